@@ -1,0 +1,28 @@
+// mc_kernels.h -- host-side launch interface of mc_kernels.hip (internal to libr3g.so)
+#ifndef R3G_MC_KERNELS_H
+#define R3G_MC_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace r3g {
+
+struct McWorkspaceLayout {
+    uint32_t nblk, nchunk, ncells;
+    uint64_t off_small, small_bytes;  // status(u32) @0, totals(2 x u64) @16, chunk sums @32
+    uint64_t off_blk, off_blkoff, off_act, off_etab;
+};
+
+size_t mc_workspace_bytes(int n0, int n1, int n2, McWorkspaceLayout* lay);
+
+// K1 + K2.  After the stream drains: status word at ws+off_small, totals {nV, nF} at +16.
+hipError_t mc_count_launch(const float* grid, int n0, int n1, int n2, double level, int classic, char* ws,
+                           const McWorkspaceLayout& lay, hipStream_t stream);
+
+// K3 + K4.  xf9 = {grid_size[3], bbox_size[3], bbox_min[3]} or null (index-space vertices).
+hipError_t mc_emit_launch(const float* grid, int n0, int n1, int n2, double level, char* ws,
+                          const McWorkspaceLayout& lay, float* verts, int32_t* faces, const double* xf9,
+                          int reversed, hipStream_t stream);
+
+}  // namespace r3g
+#endif

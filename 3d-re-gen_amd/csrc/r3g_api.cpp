@@ -1,0 +1,136 @@
+// r3g_api.cpp -- C ABI (include/r3g.h) over the HIP kernels.  Compiled with hipcc.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/r3g.h"
+#include "r3g_ctx.h"
+
+namespace r3g {
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(R3G_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int Ctx::reserve(char** buf, size_t* have, size_t need, const char* what) {
+    if (*have >= need) return R3G_OK;
+    if (*buf) {
+        hipError_t e = hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
+        if (e != hipSuccess) return hip_fail(e, what);
+    }
+    hipError_t e = hipMalloc((void**)buf, need);
+    if (e != hipSuccess) return hip_fail(e, what);
+    *have = need;
+    return R3G_OK;
+}
+}  // namespace r3g
+
+using namespace r3g;
+
+extern "C" {
+
+int r3g_version(void) { return R3G_VERSION; }
+const char* r3g_last_error(void) { return g_err; }
+
+int r3g_create(int device, r3g_ctx** out) {
+    if (!out) return fail(R3G_ERR_INVALID, "r3g_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(R3G_ERR_NO_DEVICE, "r3g_create: no HIP device visible (%s); libr3g has no CPU path",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(R3G_ERR_INVALID, "r3g_create: device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(R3G_ERR_NO_DEVICE, "r3g_create: device %d is %s, libr3g is built for gfx950 only", device,
+                    prop.gcnArchName);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return fail(R3G_ERR_HIP, "out of host memory");
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    e = hipHostMalloc((void**)&c->h_small, 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete c;
+        return hip_fail(e, "hipHostMalloc");
+    }
+    *out = reinterpret_cast<r3g_ctx*>(c);
+    return R3G_OK;
+}
+
+void r3g_destroy(r3g_ctx* ctx) {
+    if (!ctx) return;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    (void)hipSetDevice(c->device);
+    if (c->mc_ws) (void)hipFree(c->mc_ws);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    c->release_model();
+    delete c;
+}
+
+int r3g_mc_count(r3g_ctx* ctx, const float* d_grid, int n0, int n1, int n2, double level, int use_classic,
+                 int64_t* n_verts, int64_t* n_faces, void* stream) {
+    if (!ctx || !d_grid || !n_verts || !n_faces) return fail(R3G_ERR_INVALID, "r3g_mc_count: null argument");
+    if (n0 < 2 || n1 < 2 || n2 < 2) return fail(R3G_ERR_INVALID, "Input array must be at least 2x2x2.");
+    const uint64_t nnodes = (uint64_t)n0 * n1 * n2;
+    if (nnodes * 3 >= (1ull << 31)) return fail(R3G_ERR_INVALID, "r3g_mc_count: grid too large for int32 vertex ids");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    c->mc_counted = false;
+    McWorkspaceLayout lay;
+    const size_t need = mc_workspace_bytes(n0, n1, n2, &lay);
+    int rc = c->reserve(&c->mc_ws, &c->mc_ws_bytes, need, "hipMalloc(mc workspace)");
+    if (rc) return rc;
+    hipError_t e = mc_count_launch(d_grid, n0, n1, n2, level, use_classic, c->mc_ws, lay, s);
+    if (e != hipSuccess) return hip_fail(e, "mc_count_launch");
+    e = hipMemcpyAsync(c->h_small, c->mc_ws + lay.off_small, 32, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(mc totals)");
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(mc count)");
+    const unsigned status = *(const unsigned*)c->h_small;
+    const unsigned long long nv = ((const unsigned long long*)c->h_small)[2];
+    const unsigned long long nf = ((const unsigned long long*)c->h_small)[3];
+    *n_verts = (int64_t)nv;
+    *n_faces = (int64_t)nf;
+    // numpy: level < vol.min() or level > vol.max(); a NaN anywhere makes both comparisons false
+    if (!(status & 4u) && (!(status & 1u) || !(status & 2u)))
+        return fail(R3G_ERR_LEVEL_RANGE, "Surface level must be within volume data range.");
+    if (nv == 0) return fail(R3G_ERR_NO_SURFACE, "No surface found at the given iso value.");
+    c->mc_lay = lay;
+    c->mc_grid = d_grid;
+    c->mc_n[0] = n0; c->mc_n[1] = n1; c->mc_n[2] = n2;
+    c->mc_level = level;
+    c->mc_counted = true;
+    return R3G_OK;
+}
+
+int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xform, int reverse_faces,
+                void* stream) {
+    if (!ctx || !d_verts || !d_faces) return fail(R3G_ERR_INVALID, "r3g_mc_emit: null argument");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c->mc_counted) return fail(R3G_ERR_STATE, "r3g_mc_emit: no successful r3g_mc_count precedes this call");
+    hipError_t e = mc_emit_launch(c->mc_grid, c->mc_n[0], c->mc_n[1], c->mc_n[2], c->mc_level, c->mc_ws, c->mc_lay,
+                                  d_verts, d_faces, xform, reverse_faces, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "mc_emit_launch");
+    return R3G_OK;
+}
+
+}  // extern "C"
