@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import lib as _l
+from . import ffi as _l
 
 
 def _stream_ptr():
