@@ -1,0 +1,224 @@
+// attn.hip -- fused (flash) attention forward for head dim 64 on gfx950, bf16 in / fp32 softmax / bf16 out.
+//
+// Replaces F.scaled_dot_product_attention as called by upstream hunyuan3ddit.attention() (joint
+// self-attention over cat(cond, latent), L = 4442), attention_blocks.QKVMultiheadAttention (VAE,
+// L = 3072), QKVMultiheadCrossAttention (geo decoder: 257^3 query points against 3072 latents) and
+// Dinov2 self-attention; the reference reaches them from src/2d_to_3d_models/run.py:77-84.
+//
+// Formulation (everything about one query lives in lanes q and q+32 of a wave):
+//   S^T = K Q^T   : v_mfma_f32_32x32x16_bf16, A = K tile rows (LDS), B = Q^T (registers, loaded once)
+//                   -> lane (q = lane&31, h = lane>>5) holds 16 of the 32 keys of a key block
+//   softmax       : online, log2 domain, per lane + one cross-half exchange (lane ^ 32) per tile
+//   O^T += V^T P^T: A = V^T tile rows (LDS, V is produced pre-transposed by the QKV split kernel),
+//                   B = P^T taken straight from the S accumulators: the MFMA k index is mapped to
+//                   the keys a lane already holds, so no cross-lane shuffle of P is needed.
+// 4 waves x 32 queries per workgroup share the 64-key K / V^T tiles, double-buffered in LDS through
+// 16-byte LDS-DMA with the bank swizzle on the source chunk index (same scheme as gemm.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace r3g {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int KV_TILE = 64;
+constexpr int TILE_B = KV_TILE * 64 * 2;  // 8 KiB: K tile [64 keys][64 d] or V^T tile [64 d][64 keys]
+constexpr int STAGE_B = 2 * TILE_B;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7FFFu + ((ua >> 16) & 1u);
+    ub += 0x7FFFu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+
+template <bool GLDS>
+__device__ __forceinline__ void stage_kv(const uint16_t* __restrict__ Kg, const uint16_t* __restrict__ Vtg,
+                                         int64_t ldv, int key0, char* lds, int wid, int lane, int tid) {
+    if constexpr (GLDS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;  // 8 rows of 128 B
+            const int row = piece * 8 + (lane >> 3);
+            const int kc = (lane & 7) ^ ((row >> 1) & 7);
+            const uint16_t* gk = Kg + (int64_t)(key0 + row) * 64 + kc * 8;
+            const uint16_t* gv = Vtg + (int64_t)row * ldv + key0 + kc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gk,
+                                             (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv,
+                                             (__attribute__((address_space(3))) void*)(lds + TILE_B + piece * 1024), 16,
+                                             0, 0);
+        }
+    } else {
+        uint4 vk[2], vv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 256 + tid;
+            const int row = c >> 3, kc = c & 7;
+            vk[i] = *reinterpret_cast<const uint4*>(Kg + (int64_t)(key0 + row) * 64 + kc * 8);
+            vv[i] = *reinterpret_cast<const uint4*>(Vtg + (int64_t)row * ldv + key0 + kc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 256 + tid;
+            const int row = c >> 3, kc = c & 7;
+            const int off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+            *reinterpret_cast<uint4*>(lds + off) = vk[i];
+            *reinterpret_cast<uint4*>(lds + TILE_B + off) = vv[i];
+        }
+    }
+}
+
+template <bool GLDS>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = blockIdx.x * 128 + wid * 32 + ql;
+    const int kvb = p.kv_batch_stride_zero ? 0 : b;
+    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
+    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
+    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
+
+    // Q^T fragments: B operand, B[k = 8*hh + j][n = ql] = Q[q][16*ks + 8*hh + j]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)q * 64 + ks * 16 + hh * 8);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;  // scores in log2 units
+
+    // LDS read offsets.  K fragment: row = key (kb*32 + ql), chunk = 2*ks + hh.
+    // V^T fragment: row = d (db*32 + ql), first 8-byte piece at chunk 4*kb + 2*ks2, +8*hh bytes; second piece in chunk+1.
+    int offK[2], offV[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + ql;
+        offK[kb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);  // chunk hh; ks adds (2*ks)<<4 via XOR on bits 5..6
+        offV[kb] = row * 128 + ((((row >> 1) & 7)) << 4) + 8 * hh;  // chunk 0 swizzled; chunk c via XOR (c<<4)
+    }
+
+    const int ntiles = (p.Lk + KV_TILE - 1) / KV_TILE;
+    stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, 0, smem, wid, lane, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* cur = smem + (t & 1) * STAGE_B;
+        if (t + 1 < ntiles) stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
+
+        // ---- S^T = K Q^T for the two 32-key blocks
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + (offK[kb] ^ (ks << 5)));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (log2 domain); reg r of block kb <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
+        const int key_base = t * KV_TILE + 4 * hh;
+        const bool tail = (t + 1) * KV_TILE > p.Lk;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kb][r] * sc;
+                if (tail) {
+                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= p.Lk) v = -INFINITY;
+                }
+                s[kb][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[kb][r] - m_new);
+                s[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16(s[kb][8 * ks2 + 2 * e], s[kb][8 * ks2 + 2 * e + 1]);
+                const int c = 4 * kb + 2 * ks2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    union { bf16x4 h[2]; bf16x8 v; } vf;
+                    vf.h[0] = *reinterpret_cast<const bf16x4*>(cur + TILE_B + (offV[db] ^ (c << 4)));
+                    vf.h[1] = *reinterpret_cast<const bf16x4*>(cur + TILE_B + (offV[db] ^ ((c + 1) << 4)));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < p.Lq) {
+        uint16_t* dst = p.O + (int64_t)b * p.strideO + (int64_t)q * p.ldo + hd * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                pk.y = pack_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(dst + db * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+static bool g_attn_glds = true;
+void attn_set_glds(bool on) { g_attn_glds = on; }
+
+hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
+    if (p.Lq_pad % 128 || p.Lk_pad % 64 || p.Lk <= 0 || p.Lq <= 0 || p.Lk > p.Lk_pad || p.Lq > p.Lq_pad)
+        return hipErrorInvalidValue;
+    dim3 grid(p.Lq_pad / 128, p.H, p.B);
+    if (g_attn_glds) {
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace r3g

@@ -1,0 +1,110 @@
+// kernels.h -- host-side launch interface of the MFMA / elementwise kernels (internal to libr3g.so)
+#ifndef R3G_KERNELS_H
+#define R3G_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace r3g {
+
+// ------------------------------------------------------------------ GEMM (gemm.hip)
+enum GemmEpilogue {
+    EPI_BF16 = 0,            // C(bf16) = acc + bias
+    EPI_BF16_GELU_TANH = 1,  // C(bf16) = gelu_tanh(acc + bias)
+    EPI_BF16_GELU_ERF = 2,   // C(bf16) = gelu_erf(acc + bias)
+    EPI_RESID_F32 = 3,       // C(f32) += gate[b][n] * (acc + bias)      (gate null -> 1)
+    EPI_F32 = 4,             // C(f32) = acc + bias
+};
+
+struct GemmArgs {
+    const uint16_t* A;  // bf16 [batch][M][K], row stride lda, batch stride strideA (elements)
+    int64_t lda, strideA;
+    const uint16_t* W;  // bf16 [N][K], row stride ldw
+    int64_t ldw;
+    const float* bias;  // [N] or null
+    void* C;            // bf16 or f32 [batch][M][N], row stride ldc, batch stride strideC (elements)
+    int64_t ldc, strideC;
+    const float* gate;  // [batch][N] (strideGate, may be 0) or null
+    int64_t strideGate;
+    int M, N, K;        // K % 64 == 0, N % 4 == 0
+    int epi;
+};
+
+hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
+void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
+void attn_set_glds(bool on);
+
+// ------------------------------------------------------------------ attention (attn.hip)
+struct AttnArgs {
+    const uint16_t* Q;   // bf16 [B][H][Lq_pad][64]
+    const uint16_t* K;   // bf16 [B][H][Lk_pad][64]
+    const uint16_t* Vt;  // bf16 [B][H][64][Lk_pad]
+    uint16_t* O;         // bf16 [B][Lq][ldo] : head h at columns h*64 .. h*64+63
+    int64_t ldo, strideO;  // row stride and batch stride of O (elements)
+    int B, H;
+    int Lq, Lq_pad;      // valid / allocated query rows (Lq_pad % 128 == 0)
+    int Lk, Lk_pad;      // valid / allocated keys (Lk_pad % 64 == 0)
+    int kv_batch_stride_zero;  // 1: K/V are shared by all batches (cross attention with B query chunks)
+    float scale;         // softmax scale (1/sqrt(64))
+};
+
+hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
+
+// ------------------------------------------------------------------ elementwise / norms (elem.hip)
+// y(bf16)[r][c] = ((x - mean) * rstd * (w ? w[c] : 1) + (b ? b[c] : 0)) * (1 + scale[batch][c]) + shift[batch][c]
+struct LnArgs {
+    const float* x; int64_t ldx;        // f32 [rows][C]
+    uint16_t* y; int64_t ldy;           // bf16 [rows][C]
+    int64_t x_batch_stride, y_batch_stride;  // row r lives at batch (r / rows_per_batch), local row r % rows_per_batch
+    const float* w; const float* b;     // affine [C] or null
+    const float* scale; const float* shift; int64_t mod_stride;  // per-batch [C] or null
+    int rows, C, rows_per_batch;
+    float eps;
+};
+hipError_t layernorm_launch(const LnArgs& p, hipStream_t s);
+
+enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
+// Split a fused projection output into attention operands, normalising q and k per head (dim 64).
+struct QkvSplitArgs {
+    const uint16_t* src; int64_t ld; int64_t src_batch_stride;  // bf16 [B][L][ld]
+    int q_off, k_off, v_off;   // column of head 0 / dim 0 for q, k, v (-1: absent)
+    int head_stride;           // column distance between consecutive heads
+    uint16_t* Q; uint16_t* K; uint16_t* Vt;   // destinations (may be null when absent)
+    int Lq_pad, Lk_pad;        // allocated rows of Q and of K/Vt
+    int dst_row0;              // first destination row (token offset inside the joint sequence)
+    int B, H, L;               // L source tokens per batch
+    int norm;                  // QkNorm
+    const float* qw; const float* qb; const float* kw; const float* kb;  // [64] scale / bias
+    float eps;
+};
+hipError_t qkv_split_launch(const QkvSplitArgs& p, hipStream_t s);
+
+// y[b][n] = act(x[b][:] . W[n][:] + bias[n]); x f32 [B][K], W bf16 [N][K], y f32; B <= 8
+hipError_t gemv_launch(const float* x, int B, int K, const uint16_t* W, int64_t ldw, const float* bias, float* y,
+                       int N, int act_silu_in, int act_silu_out, hipStream_t s);
+
+// t == null: every batch entry uses t_scalar
+hipError_t timestep_embedding_launch(const float* t, float t_scalar, int B, float time_factor, float* out /*[B][256]*/,
+                                     hipStream_t s);
+// out(bf16)[r][c] = in(f32)[r][c] for c < C, 0 for C <= c < Cpad
+hipError_t cast_pad_launch(const float* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int C, int Cpad,
+                           float scale, hipStream_t s);
+// x(f32)[b][r][c] = v(bf16/f32) broadcast helpers
+hipError_t fill_rows_launch(float* dst, int64_t ld, int rows, int C, const float* row_values, hipStream_t s);
+// latents += dsigma * (v_u + g (v_c - v_u));  v = [2][n] (cond first)
+hipError_t cfg_euler_launch(float* latents, const float* v2, int64_t n, float guidance, float dsigma, hipStream_t s);
+// swiglu: out(bf16)[r][c] = silu(in[r][c]) * in[r][F + c]
+hipError_t swiglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
+// Fourier features of dense grid points [start, start+count): bf16 [count][64] = (xyz, sin(x 2^k).., cos.., 0 pad)
+hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, double bound, int num_freqs,
+                               int include_pi, hipStream_t s);
+// logits[r] = LN(x[r]) . w + b  (ln_post + output_proj fused);  x f32 [rows][C]
+hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb, float eps,
+                         const float* w, float b, float* out, hipStream_t s);
+// DINOv2 patch embedding im2col: image f32 [3][S][S] -> bf16 [P*P][Kpad], K = 3*ps*ps ordered (c, dy, dx)
+hipError_t im2col_launch(const float* img, int S, int ps, uint16_t* out, int Kpad, hipStream_t s);
+// x(f32)[r][c] = a(f32)[r][c] (+ pos[r][c]) ; assorted small helpers
+hipError_t add_rows_launch(float* x, int64_t ldx, const float* pos, int64_t ldp, int rows, int C, hipStream_t s);
+hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStream_t s);
+
+}  // namespace r3g
+#endif

@@ -1,0 +1,632 @@
+// model.cpp -- host-side orchestration of the Hunyuan3D-2 shape model on one MI355X (compiled by hipcc).
+//
+// Mirrors, kernel launch by kernel launch, what the reference obtains from `hy3dgen`
+// (src/2d_to_3d_models/run.py:77-84 -> Hunyuan3DDiTFlowMatchingPipeline.__call__):
+//   cond_encode  : conditioner.DinoImageEncoder (transformers Dinov2Model) -> cond tokens
+//   dit_forward  : denoisers/hunyuan3ddit.py Hunyuan3DDiT.forward
+//   flow_sample  : pipelines.py denoising loop (CFG batch 2) + schedulers.FlowMatchEulerDiscreteScheduler.step
+//   vae_decode   : autoencoders/model.py ShapeVAE.forward (post_kl + Transformer) + geo-decoder K/V (once)
+//   grid_query   : volume_decoders.VanillaVolumeDecoder + attention_blocks.CrossAttentionDecoder
+// Weights are registered by their upstream state-dict names; all dimensions come from r3g_model_config.
+//
+// Token layout (differs from upstream on purpose): softmax attention has no positional term on this
+// path, so the joint sequence is stored [latent | cond | pad] (upstream: cat(cond, latent)); latent rows
+// start at 0 (tile aligned), cond rows at num_latents, padded keys are masked inside the kernel.
+// The residual stream is fp32 in HBM; GEMM operands are bf16; accumulation fp32.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/r3g.h"
+#include "kernels.h"
+#include "r3g_ctx.h"
+
+namespace r3g {
+
+struct Tensor {
+    const void* p;
+    int dtype;  // 0 f32, 1 bf16
+    int64_t rows, cols;
+};
+
+struct Lin {
+    const uint16_t* w = nullptr;
+    const float* b = nullptr;
+    int N = 0, K = 0;
+    int64_t ldw = 0;
+};
+
+static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct Model {
+    r3g_model_config c{};
+    std::unordered_map<std::string, Tensor> w;
+    std::unordered_map<std::string, float> scalars;
+    // derived
+    int T = 0, Tpad = 0, Lc = 0, Lcpad = 0, H = 0, Hd = 0, W = 0, Wh = 0, Hc = 0, Hch = 0, Fc = 0;
+    int cin_pad = 0, qc = 0;
+    // device buffers
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    float* f32a = nullptr;      // residual stream
+    uint16_t* xn = nullptr;     // normalised / modulated operand
+    uint16_t* qkv = nullptr;    // fused projection output
+    uint16_t *Q = nullptr, *K = nullptr, *Vt = nullptr;
+    uint16_t* cat = nullptr;    // [attn | mlp hidden] operand of the closing projection
+    uint16_t* hid = nullptr;    // wide hidden (VAE / geo / DINO MLP)
+    uint16_t* inb = nullptr;    // bf16 copy of small inputs (latents, Fourier features, patches)
+    float* small = nullptr;     // temb[B][256] | th[B][H] | vec[B][H] | mods[B][12H] | v2[2][N][Cin] ...
+    float *temb = nullptr, *th = nullptr, *vec = nullptr, *mods = nullptr, *v2 = nullptr;
+    // persistent results
+    float* z = nullptr;         // VAE-decoded latents f32 [Nlat][W]
+    uint16_t *geoK = nullptr, *geoVt = nullptr;
+    bool have_z = false;
+    std::string err;
+
+    const Tensor* find(const std::string& name) const {
+        auto it = w.find(name);
+        return it == w.end() ? nullptr : &it->second;
+    }
+};
+
+static std::string fmt(const char* f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define R3G_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);    \
+    } while (0)
+#define R3G_RC(expr)                \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__) return rc__;      \
+    } while (0)
+
+// ---- weight lookup ---------------------------------------------------------------------------------
+static int get_lin(const Model& m, const std::string& base, bool need_bias, Lin* out) {
+    const Tensor* w = m.find(base + ".weight");
+    if (!w || w->dtype != 1) return fail(R3G_ERR_STATE, "missing bf16 weight '%s.weight'", base.c_str());
+    out->w = (const uint16_t*)w->p;
+    out->N = (int)w->rows;
+    out->K = (int)w->cols;
+    out->ldw = w->cols;
+    if (out->K % 64) return fail(R3G_ERR_INVALID, "'%s.weight' K=%d is not padded to a multiple of 64", base.c_str(), out->K);
+    const Tensor* b = m.find(base + ".bias");
+    out->b = b ? (const float*)b->p : nullptr;
+    if (b && b->dtype != 0) return fail(R3G_ERR_INVALID, "'%s.bias' must be f32", base.c_str());
+    if (need_bias && !b) return fail(R3G_ERR_STATE, "missing '%s.bias'", base.c_str());
+    return R3G_OK;
+}
+
+static int get_vec(const Model& m, const std::string& name, int64_t n, const float** out) {
+    const Tensor* t = m.find(name);
+    if (!t || t->dtype != 0) return fail(R3G_ERR_STATE, "missing f32 tensor '%s'", name.c_str());
+    if (n > 0 && t->rows * t->cols != n) return fail(R3G_ERR_INVALID, "'%s' has %lld elements, expected %lld", name.c_str(),
+                                                     (long long)(t->rows * t->cols), (long long)n);
+    *out = (const float*)t->p;
+    return R3G_OK;
+}
+
+// ---- thin launch helpers -----------------------------------------------------------------------------
+static int gemm(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, int n_off, int N, void* C, int64_t ldc,
+                int64_t strideC, int M, int K, int epi, const float* gate, int64_t strideGate, int batch, hipStream_t s) {
+    if (K > l.K) return fail(R3G_ERR_INVALID, "gemm: K=%d exceeds weight K=%d", K, l.K);
+    GemmArgs p{};
+    p.A = A; p.lda = lda; p.strideA = strideA;
+    p.W = l.w + (int64_t)n_off * l.ldw; p.ldw = l.ldw;
+    p.bias = l.b ? l.b + n_off : nullptr;
+    p.C = C; p.ldc = ldc; p.strideC = strideC;
+    p.gate = gate; p.strideGate = strideGate;
+    p.M = M; p.N = N; p.K = K; p.epi = epi;
+    hipError_t e = gemm_launch(p, batch, s);
+    if (e != hipSuccess) return hip_fail(e, "gemm_launch");
+    return R3G_OK;
+}
+
+static int layernorm(const float* x, int64_t ldx, int64_t xbs, uint16_t* y, int64_t ldy, int64_t ybs, int rows_per_batch,
+                     int batch, int C, const float* w, const float* b, const float* scale, const float* shift,
+                     int64_t mod_stride, float eps, hipStream_t s) {
+    LnArgs p{};
+    p.x = x; p.ldx = ldx; p.x_batch_stride = xbs;
+    p.y = y; p.ldy = ldy; p.y_batch_stride = ybs;
+    p.w = w; p.b = b; p.scale = scale; p.shift = shift; p.mod_stride = mod_stride;
+    p.rows = rows_per_batch * batch; p.C = C; p.rows_per_batch = rows_per_batch; p.eps = eps;
+    hipError_t e = layernorm_launch(p, s);
+    if (e != hipSuccess) return hip_fail(e, "layernorm_launch");
+    return R3G_OK;
+}
+
+static int attention(const Model& m, int B, int heads, int Lq, int Lq_pad, int Lk, int Lk_pad, uint16_t* O, int64_t ldo,
+                     int64_t strideO, const uint16_t* Kp, const uint16_t* Vtp, bool shared_kv, hipStream_t s) {
+    AttnArgs p{};
+    p.Q = m.Q; p.K = Kp; p.Vt = Vtp; p.O = O; p.ldo = ldo; p.strideO = strideO;
+    p.B = B; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
+    p.kv_batch_stride_zero = shared_kv ? 1 : 0;
+    p.scale = 0.125f;
+    hipError_t e = attention_launch(p, s);
+    if (e != hipSuccess) return hip_fail(e, "attention_launch");
+    return R3G_OK;
+}
+
+// ---- DiT -------------------------------------------------------------------------------------------
+// Modulation.forward: lin(silu(vec)) -> dst f32 [B][mult*H]
+static int dit_modulation(Model& m, const std::string& base, int B, int mult, float* dst, hipStream_t s) {
+    Lin l;
+    R3G_RC(get_lin(m, base, true, &l));
+    if (l.N != mult * m.H) return fail(R3G_ERR_INVALID, "'%s' has N=%d, expected %d", base.c_str(), l.N, mult * m.H);
+    R3G_TRY(gemv_launch(m.vec, B, m.H, l.w, l.ldw, l.b, dst, l.N, 1, 0, s));
+    return R3G_OK;
+}
+
+static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_scalar, const uint16_t* cond, float* out,
+                       int B, int n_double, int n_single, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    const int H = m.H, Nl = c.vae_num_latents, Lc = m.Lc, T = m.T, Tpad = m.Tpad, heads = m.Hd;
+    const int64_t xs = (int64_t)Tpad * H;  // batch stride of the residual stream
+    if (B < 1 || B > 2) return fail(R3G_ERR_INVALID, "dit_forward: batch %d not in [1,2]", B);
+    Lin l;
+    // latent_in / cond_in -> joint residual stream [latent | cond]
+    R3G_TRY(cast_pad_launch(x_in, c.dit_in_channels, m.inb, m.cin_pad, B * Nl, c.dit_in_channels, m.cin_pad, 1.0f, s));
+    R3G_RC(get_lin(m, "model.latent_in", true, &l));
+    R3G_RC(gemm(m.inb, m.cin_pad, (int64_t)Nl * m.cin_pad, l, 0, H, m.f32a, H, xs, Nl, m.cin_pad, EPI_F32, nullptr, 0, B, s));
+    R3G_RC(get_lin(m, "model.cond_in", true, &l));
+    R3G_RC(gemm(cond, c.dit_context_dim, (int64_t)Lc * c.dit_context_dim, l, 0, H, m.f32a + (int64_t)Nl * H, H, xs, Lc,
+                c.dit_context_dim, EPI_F32, nullptr, 0, B, s));
+    // vec = time_in(timestep_embedding(t))
+    R3G_TRY(timestep_embedding_launch(t_dev, t_scalar, B, c.dit_time_factor, m.temb, s));
+    R3G_RC(get_lin(m, "model.time_in.in_layer", true, &l));
+    R3G_TRY(gemv_launch(m.temb, B, 256, l.w, l.ldw, l.b, m.th, H, 0, 1, s));
+    R3G_RC(get_lin(m, "model.time_in.out_layer", true, &l));
+    R3G_TRY(gemv_launch(m.th, B, H, l.w, l.ldw, l.b, m.vec, H, 0, 0, s));
+
+    const int nd = n_double < 0 ? c.dit_depth_double : n_double;
+    const int ns = n_single < 0 ? c.dit_depth_single : n_single;
+    const int64_t catld = 5 * (int64_t)H, cats = (int64_t)Tpad * catld;
+    const int64_t qkvld = 3 * (int64_t)H, qkvs = (int64_t)Tpad * qkvld;
+    const int mh = c.dit_mlp_hidden;
+    if (mh != 4 * H) return fail(R3G_ERR_INVALID, "dit mlp_hidden must be 4*hidden");
+
+    for (int i = 0; i < nd; ++i) {
+        // stream 0 = img (latent rows [0,Nl)), stream 1 = txt (cond rows [Nl, Nl+Lc))
+        for (int st = 0; st < 2; ++st) {
+            const char* nm = st == 0 ? "img" : "txt";
+            const int row0 = st == 0 ? 0 : Nl, rows = st == 0 ? Nl : Lc;
+            const std::string blk = fmt("model.double_blocks.%d.%s", i, nm);
+            // mods: [stream][B][6H] = shift1 scale1 gate1 shift2 scale2 gate2
+            float* mm = m.mods + (int64_t)st * 2 * 6 * H;
+            R3G_RC(dit_modulation(m, blk + "_mod.lin", B, 6, mm, s));
+            R3G_RC(layernorm(m.f32a + (int64_t)row0 * H, H, xs, m.xn + (int64_t)row0 * H, H, xs, rows, B, H, nullptr, nullptr,
+                             mm + H, mm, 6 * H, 1e-6f, s));
+            R3G_RC(get_lin(m, blk + "_attn.qkv", c.dit_qkv_bias != 0, &l));
+            R3G_RC(gemm(m.xn + (int64_t)row0 * H, H, xs, l, 0, 3 * H, m.qkv + (int64_t)row0 * qkvld, qkvld, qkvs, rows, H,
+                        EPI_BF16, nullptr, 0, B, s));
+            QkvSplitArgs q{};
+            q.src = m.qkv + (int64_t)row0 * qkvld; q.ld = qkvld; q.src_batch_stride = qkvs;
+            q.q_off = 0; q.k_off = H; q.v_off = 2 * H; q.head_stride = 64;
+            q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Tpad; q.Lk_pad = Tpad; q.dst_row0 = row0;
+            q.B = B; q.H = heads; q.L = rows; q.norm = QKN_RMS; q.eps = 1e-6f;
+            R3G_RC(get_vec(m, blk + "_attn.norm.query_norm.scale", 64, &q.qw));
+            R3G_RC(get_vec(m, blk + "_attn.norm.key_norm.scale", 64, &q.kw));
+            R3G_TRY(qkv_split_launch(q, s));
+        }
+        R3G_RC(attention(m, B, heads, T, Tpad, T, Tpad, m.cat, catld, cats, m.K, m.Vt, false, s));
+        for (int st = 0; st < 2; ++st) {
+            const char* nm = st == 0 ? "img" : "txt";
+            const int row0 = st == 0 ? 0 : Nl, rows = st == 0 ? Nl : Lc;
+            const std::string blk = fmt("model.double_blocks.%d.%s", i, nm);
+            float* mm = m.mods + (st == 0 ? 0 : (int64_t)2 * 6 * H);
+            float* xr = m.f32a + (int64_t)row0 * H;
+            R3G_RC(get_lin(m, blk + "_attn.proj", true, &l));
+            R3G_RC(gemm(m.cat + (int64_t)row0 * catld, catld, cats, l, 0, H, xr, H, xs, rows, H, EPI_RESID_F32, mm + 2 * H,
+                        6 * H, B, s));
+            R3G_RC(layernorm(xr, H, xs, m.xn + (int64_t)row0 * H, H, xs, rows, B, H, nullptr, nullptr, mm + 4 * H, mm + 3 * H,
+                             6 * H, 1e-6f, s));
+            R3G_RC(get_lin(m, blk + "_mlp.0", true, &l));
+            R3G_RC(gemm(m.xn + (int64_t)row0 * H, H, xs, l, 0, mh, m.cat + (int64_t)row0 * catld + H, catld, cats, rows, H,
+                        EPI_BF16_GELU_TANH, nullptr, 0, B, s));
+            R3G_RC(get_lin(m, blk + "_mlp.2", true, &l));
+            R3G_RC(gemm(m.cat + (int64_t)row0 * catld + H, catld, cats, l, 0, H, xr, H, xs, rows, mh, EPI_RESID_F32,
+                        mm + 5 * H, 6 * H, B, s));
+        }
+    }
+    for (int i = 0; i < ns; ++i) {
+        const std::string blk = fmt("model.single_blocks.%d", i);
+        float* mm = m.mods;  // [B][3H]: shift scale gate
+        R3G_RC(dit_modulation(m, blk + ".modulation.lin", B, 3, mm, s));
+        R3G_RC(layernorm(m.f32a, H, xs, m.xn, H, xs, T, B, H, nullptr, nullptr, mm + H, mm, 3 * H, 1e-6f, s));
+        R3G_RC(get_lin(m, blk + ".linear1", true, &l));
+        if (l.N != 3 * H + mh) return fail(R3G_ERR_INVALID, "linear1 N mismatch");
+        R3G_RC(gemm(m.xn, H, xs, l, 0, 3 * H, m.qkv, qkvld, qkvs, T, H, EPI_BF16, nullptr, 0, B, s));
+        R3G_RC(gemm(m.xn, H, xs, l, 3 * H, mh, m.cat + H, catld, cats, T, H, EPI_BF16_GELU_TANH, nullptr, 0, B, s));
+        QkvSplitArgs q{};
+        q.src = m.qkv; q.ld = qkvld; q.src_batch_stride = qkvs;
+        q.q_off = 0; q.k_off = H; q.v_off = 2 * H; q.head_stride = 64;
+        q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Tpad; q.Lk_pad = Tpad; q.dst_row0 = 0;
+        q.B = B; q.H = heads; q.L = T; q.norm = QKN_RMS; q.eps = 1e-6f;
+        R3G_RC(get_vec(m, blk + ".norm.query_norm.scale", 64, &q.qw));
+        R3G_RC(get_vec(m, blk + ".norm.key_norm.scale", 64, &q.kw));
+        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(attention(m, B, heads, T, Tpad, T, Tpad, m.cat, catld, cats, m.K, m.Vt, false, s));
+        R3G_RC(get_lin(m, blk + ".linear2", true, &l));
+        R3G_RC(gemm(m.cat, catld, cats, l, 0, H, m.f32a, H, xs, T, H + mh, EPI_RESID_F32, mm + 2 * H, 3 * H, B, s));
+    }
+    // final layer on the latent rows
+    R3G_RC(get_lin(m, "model.final_layer.adaLN_modulation.1", true, &l));
+    R3G_TRY(gemv_launch(m.vec, B, H, l.w, l.ldw, l.b, m.mods, 2 * H, 1, 0, s));
+    R3G_RC(layernorm(m.f32a, H, xs, m.xn, H, xs, Nl, B, H, nullptr, nullptr, m.mods + H, m.mods, 2 * H, 1e-6f, s));
+    R3G_RC(get_lin(m, "model.final_layer.linear", true, &l));
+    R3G_RC(gemm(m.xn, H, xs, l, 0, c.dit_in_channels, out, c.dit_in_channels, (int64_t)Nl * c.dit_in_channels, Nl, H, EPI_F32,
+                nullptr, 0, B, s));
+    return R3G_OK;
+}
+
+// ---- VAE transformer + geo-decoder K/V -------------------------------------------------------------
+static int vae_decode(Model& m, const float* latents, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    const int W = m.W, Nl = c.vae_num_latents, heads = m.Wh;
+    Lin l;
+    R3G_TRY(cast_pad_launch(latents, c.vae_embed_dim, m.inb, m.cin_pad, Nl, c.vae_embed_dim, m.cin_pad,
+                            1.0f / c.vae_scale_factor, s));
+    R3G_RC(get_lin(m, "vae.post_kl", true, &l));
+    R3G_RC(gemm(m.inb, m.cin_pad, 0, l, 0, W, m.z, W, 0, Nl, m.cin_pad, EPI_F32, nullptr, 0, 1, s));
+    const float *lw, *lb;
+    for (int i = 0; i < c.vae_layers; ++i) {
+        const std::string blk = fmt("vae.transformer.resblocks.%d", i);
+        R3G_RC(get_vec(m, blk + ".ln_1.weight", W, &lw));
+        R3G_RC(get_vec(m, blk + ".ln_1.bias", W, &lb));
+        R3G_RC(layernorm(m.z, W, 0, m.xn, W, 0, Nl, 1, W, lw, lb, nullptr, nullptr, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, blk + ".attn.c_qkv", c.vae_qkv_bias != 0, &l));
+        R3G_RC(gemm(m.xn, W, 0, l, 0, 3 * W, m.qkv, 3 * W, 0, Nl, W, EPI_BF16, nullptr, 0, 1, s));
+        QkvSplitArgs q{};
+        q.src = m.qkv; q.ld = 3 * W; q.src_batch_stride = 0;
+        q.q_off = 0; q.k_off = 64; q.v_off = 128; q.head_stride = 192;  // per-head interleaved (q,k,v)
+        q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = (int)rup(Nl, 128); q.Lk_pad = (int)rup(Nl, 128); q.dst_row0 = 0;
+        q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f;
+        q.norm = c.vae_qk_norm ? QKN_LAYERNORM : QKN_NONE;
+        if (c.vae_qk_norm) {
+            R3G_RC(get_vec(m, blk + ".attn.attention.q_norm.weight", 64, &q.qw));
+            R3G_RC(get_vec(m, blk + ".attn.attention.q_norm.bias", 64, &q.qb));
+            R3G_RC(get_vec(m, blk + ".attn.attention.k_norm.weight", 64, &q.kw));
+            R3G_RC(get_vec(m, blk + ".attn.attention.k_norm.bias", 64, &q.kb));
+        }
+        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(attention(m, 1, heads, Nl, q.Lq_pad, Nl, q.Lk_pad, m.cat, W, 0, m.K, m.Vt, false, s));
+        R3G_RC(get_lin(m, blk + ".attn.c_proj", true, &l));
+        R3G_RC(gemm(m.cat, W, 0, l, 0, W, m.z, W, 0, Nl, W, EPI_RESID_F32, nullptr, 0, 1, s));
+        R3G_RC(get_vec(m, blk + ".ln_2.weight", W, &lw));
+        R3G_RC(get_vec(m, blk + ".ln_2.bias", W, &lb));
+        R3G_RC(layernorm(m.z, W, 0, m.xn, W, 0, Nl, 1, W, lw, lb, nullptr, nullptr, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, blk + ".mlp.c_fc", true, &l));
+        R3G_RC(gemm(m.xn, W, 0, l, 0, 4 * W, m.hid, 4 * W, 0, Nl, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+        R3G_RC(get_lin(m, blk + ".mlp.c_proj", true, &l));
+        R3G_RC(gemm(m.hid, 4 * W, 0, l, 0, W, m.z, W, 0, Nl, 4 * W, EPI_RESID_F32, nullptr, 0, 1, s));
+    }
+    // geo decoder: K / V^T of the latents, computed ONCE (upstream recomputes c_kv for every query chunk)
+    const std::string g = "vae.geo_decoder.cross_attn_decoder";
+    R3G_RC(get_vec(m, g + ".ln_2.weight", W, &lw));
+    R3G_RC(get_vec(m, g + ".ln_2.bias", W, &lb));
+    R3G_RC(layernorm(m.z, W, 0, m.xn, W, 0, Nl, 1, W, lw, lb, nullptr, nullptr, 0, 1e-6f, s));
+    R3G_RC(get_lin(m, g + ".attn.c_kv", c.vae_qkv_bias != 0, &l));
+    R3G_RC(gemm(m.xn, W, 0, l, 0, 2 * W, m.qkv, 2 * W, 0, Nl, W, EPI_BF16, nullptr, 0, 1, s));
+    QkvSplitArgs q{};
+    q.src = m.qkv; q.ld = 2 * W; q.src_batch_stride = 0;
+    q.q_off = -1; q.k_off = 0; q.v_off = 64; q.head_stride = 128;  // per-head interleaved (k,v)
+    q.Q = nullptr; q.K = m.geoK; q.Vt = m.geoVt; q.Lq_pad = 0; q.Lk_pad = (int)rup(Nl, 64); q.dst_row0 = 0;
+    q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f;
+    const bool qkn = c.vae_qk_norm && c.vae_ln_post;
+    q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
+    if (qkn) {
+        R3G_RC(get_vec(m, g + ".attn.attention.k_norm.weight", 64, &q.kw));
+        R3G_RC(get_vec(m, g + ".attn.attention.k_norm.bias", 64, &q.kb));
+    }
+    R3G_TRY(qkv_split_launch(q, s));
+    m.have_z = true;
+    return R3G_OK;
+}
+
+static int grid_query(Model& m, double bound, int R, float* grid, int64_t start, int64_t count, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    if (!m.have_z) return fail(R3G_ERR_STATE, "r3g_grid_query: r3g_vae_decode has not run");
+    const int W = m.W, Nl = c.vae_num_latents, heads = m.Wh;
+    const int64_t total = (int64_t)(R + 1) * (R + 1) * (R + 1);
+    if (start < 0 || count < 0 || start + count > total) return fail(R3G_ERR_INVALID, "grid_query: range outside the grid");
+    const std::string g = "vae.geo_decoder";
+    Lin lq, lcq, lproj, lfc, lfp;
+    R3G_RC(get_lin(m, g + ".query_proj", true, &lq));
+    R3G_RC(get_lin(m, g + ".cross_attn_decoder.attn.c_q", c.vae_qkv_bias != 0, &lcq));
+    R3G_RC(get_lin(m, g + ".cross_attn_decoder.attn.c_proj", true, &lproj));
+    R3G_RC(get_lin(m, g + ".cross_attn_decoder.mlp.c_fc", true, &lfc));
+    R3G_RC(get_lin(m, g + ".cross_attn_decoder.mlp.c_proj", true, &lfp));
+    const float *l1w, *l1b, *l3w, *l3b, *lpw = nullptr, *lpb = nullptr, *ow;
+    R3G_RC(get_vec(m, g + ".cross_attn_decoder.ln_1.weight", W, &l1w));
+    R3G_RC(get_vec(m, g + ".cross_attn_decoder.ln_1.bias", W, &l1b));
+    R3G_RC(get_vec(m, g + ".cross_attn_decoder.ln_3.weight", W, &l3w));
+    R3G_RC(get_vec(m, g + ".cross_attn_decoder.ln_3.bias", W, &l3b));
+    if (c.vae_ln_post) {
+        R3G_RC(get_vec(m, g + ".ln_post.weight", W, &lpw));
+        R3G_RC(get_vec(m, g + ".ln_post.bias", W, &lpb));
+    }
+    R3G_RC(get_vec(m, g + ".output_proj.weight", W, &ow));
+    auto obi = m.scalars.find(g + ".output_proj.bias");
+    if (obi == m.scalars.end()) return fail(R3G_ERR_STATE, "missing scalar '%s.output_proj.bias'", g.c_str());
+    const float ob = obi->second;
+    const bool qkn = c.vae_qk_norm && c.vae_ln_post;
+    const int Lkp = (int)rup(Nl, 64);
+    for (int64_t off = 0; off < count; off += m.qc) {
+        const int n = (int)std::min<int64_t>(m.qc, count - off);
+        const int npad = (int)rup(n, 128);
+        R3G_TRY(fourier_grid_launch(m.inb, start + off, npad, R, bound, c.vae_num_freqs, c.vae_include_pi, s));
+        R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, EPI_F32, nullptr, 0, 1, s));
+        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s));
+        R3G_RC(gemm(m.xn, W, 0, lcq, 0, W, m.qkv, W, 0, n, W, EPI_BF16, nullptr, 0, 1, s));
+        QkvSplitArgs q{};
+        q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
+        q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
+        q.Q = m.Q; q.K = nullptr; q.Vt = nullptr; q.Lq_pad = npad; q.Lk_pad = 0; q.dst_row0 = 0;
+        q.B = 1; q.H = heads; q.L = n; q.eps = 1e-6f;
+        q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
+        if (qkn) {
+            R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
+            R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
+        }
+        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
+        R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, EPI_RESID_F32, nullptr, 0, 1, s));
+        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s));
+        R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+        R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, EPI_RESID_F32, nullptr, 0, 1, s));
+        R3G_TRY(ln_dot_launch(m.f32a, W, n, W, c.vae_ln_post, lpw, lpb, 1e-5f, ow, ob, grid + start + off, s));
+    }
+    return R3G_OK;
+}
+
+// ---- conditioner (Dinov2) ----------------------------------------------------------------------------
+static int cond_encode(Model& m, const float* img, uint16_t* out, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    const int Hc = m.Hc, heads = m.Hch, S = c.cond_image_size, ps = c.cond_patch, P = S / ps, L = m.Lc, Lp = m.Lcpad;
+    const std::string e = "conditioner.main_image_encoder.model";
+    Lin l;
+    R3G_RC(get_lin(m, e + ".embeddings.patch_embeddings.projection", true, &l));
+    R3G_TRY(im2col_launch(img, S, ps, m.inb, l.K, s));
+    R3G_RC(gemm(m.inb, l.K, 0, l, 0, Hc, m.f32a + Hc, Hc, 0, P * P, l.K, EPI_F32, nullptr, 0, 1, s));
+    const float *cls, *pos;
+    R3G_RC(get_vec(m, e + ".embeddings.cls_token", Hc, &cls));
+    R3G_RC(get_vec(m, e + ".embeddings.position_embeddings", (int64_t)L * Hc, &pos));
+    R3G_TRY(fill_rows_launch(m.f32a, Hc, 1, Hc, cls, s));
+    R3G_TRY(add_rows_launch(m.f32a, Hc, pos, Hc, L, Hc, s));
+    const float *w, *b, *ls;
+    for (int i = 0; i < c.cond_layers; ++i) {
+        const std::string blk = fmt("%s.encoder.layer.%d", e.c_str(), i);
+        R3G_RC(get_vec(m, blk + ".norm1.weight", Hc, &w));
+        R3G_RC(get_vec(m, blk + ".norm1.bias", Hc, &b));
+        R3G_RC(layernorm(m.f32a, Hc, 0, m.xn, Hc, 0, L, 1, Hc, w, b, nullptr, nullptr, 0, c.cond_ln_eps, s));
+        R3G_RC(get_lin(m, blk + ".attention.attention.qkv", true, &l));
+        R3G_RC(gemm(m.xn, Hc, 0, l, 0, 3 * Hc, m.qkv, 3 * Hc, 0, L, Hc, EPI_BF16, nullptr, 0, 1, s));
+        QkvSplitArgs q{};
+        q.src = m.qkv; q.ld = 3 * Hc; q.src_batch_stride = 0;
+        q.q_off = 0; q.k_off = Hc; q.v_off = 2 * Hc; q.head_stride = 64;
+        q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Lp; q.Lk_pad = Lp; q.dst_row0 = 0;
+        q.B = 1; q.H = heads; q.L = L; q.norm = QKN_NONE; q.eps = 0.f;
+        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(attention(m, 1, heads, L, Lp, L, Lp, m.cat, Hc, 0, m.K, m.Vt, false, s));
+        R3G_RC(get_lin(m, blk + ".attention.output.dense", true, &l));
+        R3G_RC(get_vec(m, blk + ".layer_scale1.lambda1", Hc, &ls));
+        R3G_RC(gemm(m.cat, Hc, 0, l, 0, Hc, m.f32a, Hc, 0, L, Hc, EPI_RESID_F32, ls, 0, 1, s));
+        R3G_RC(get_vec(m, blk + ".norm2.weight", Hc, &w));
+        R3G_RC(get_vec(m, blk + ".norm2.bias", Hc, &b));
+        R3G_RC(layernorm(m.f32a, Hc, 0, m.xn, Hc, 0, L, 1, Hc, w, b, nullptr, nullptr, 0, c.cond_ln_eps, s));
+        R3G_RC(get_lin(m, blk + ".mlp.weights_in", true, &l));
+        if (l.N != 2 * m.Fc) return fail(R3G_ERR_INVALID, "Dinov2 SwiGLU weights_in N=%d, expected %d", l.N, 2 * m.Fc);
+        R3G_RC(gemm(m.xn, Hc, 0, l, 0, 2 * m.Fc, m.hid, 2 * m.Fc, 0, L, Hc, EPI_BF16, nullptr, 0, 1, s));
+        uint16_t* h2 = m.hid + (int64_t)Lp * 2 * m.Fc;
+        R3G_TRY(swiglu_launch(m.hid, 2 * m.Fc, h2, m.Fc, L, m.Fc, s));
+        R3G_RC(get_lin(m, blk + ".mlp.weights_out", true, &l));
+        R3G_RC(get_vec(m, blk + ".layer_scale2.lambda1", Hc, &ls));
+        R3G_RC(gemm(h2, m.Fc, 0, l, 0, Hc, m.f32a, Hc, 0, L, m.Fc, EPI_RESID_F32, ls, 0, 1, s));
+    }
+    R3G_RC(get_vec(m, e + ".layernorm.weight", Hc, &w));
+    R3G_RC(get_vec(m, e + ".layernorm.bias", Hc, &b));
+    R3G_RC(layernorm(m.f32a, Hc, 0, out, Hc, 0, L, 1, Hc, w, b, nullptr, nullptr, 0, c.cond_ln_eps, s));
+    return R3G_OK;
+}
+
+// ---- lifetime ----------------------------------------------------------------------------------------
+static void model_free(Model* m) {
+    if (!m) return;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+
+static int model_create(Ctx* ctx, const r3g_model_config* cfg) {
+    if (ctx->model) { model_free((Model*)ctx->model); ctx->model = nullptr; }
+    Model* m = new Model();
+    m->c = *cfg;
+    const r3g_model_config& c = m->c;
+    m->H = c.dit_hidden; m->Hd = c.dit_heads; m->W = c.vae_width; m->Wh = c.vae_heads;
+    m->Hc = c.cond_hidden; m->Hch = c.cond_heads; m->Fc = c.cond_ffn_hidden;
+    const int P = c.cond_image_size / c.cond_patch;
+    m->Lc = P * P + 1;
+    m->Lcpad = (int)rup(m->Lc, 128);
+    m->T = c.vae_num_latents + m->Lc;
+    m->Tpad = (int)rup(m->T, 128);
+    m->cin_pad = (int)rup(std::max(c.dit_in_channels, c.vae_embed_dim), 64);
+    m->qc = c.grid_chunk > 0 ? (int)rup(c.grid_chunk, 128) : 131072;
+    auto bad = [&](const char* what) { model_free(m); return fail(R3G_ERR_INVALID, "r3g_model_create: %s", what); };
+    if (m->H != 64 * m->Hd || m->W != 64 * m->Wh || m->Hc != 64 * m->Hch) return bad("every attention here needs head_dim == 64");
+    if (m->H % 64 || m->W % 64 || m->Hc % 64 || m->Fc % 64 || c.dit_context_dim % 64) return bad("hidden sizes must be multiples of 64");
+    if (c.vae_num_latents % 64) return bad("num_latents must be a multiple of 64");
+    if (c.dit_context_dim != m->Hc) return bad("dit_context_dim must equal the conditioner hidden size");
+    if (c.dit_in_channels != c.vae_embed_dim) return bad("dit_in_channels must equal vae_embed_dim");
+    if (c.dit_in_channels % 4) return bad("in_channels must be a multiple of 4");
+    const int H = m->H, W = m->W, Hc = m->Hc, Nl = c.vae_num_latents, Tp = m->Tpad, Lp = m->Lcpad, qc = m->qc;
+    const int Nlp = (int)rup(Nl, 128);
+    const int64_t Kpatch = rup(3 * c.cond_patch * c.cond_patch, 64);
+    auto mx = [](std::initializer_list<int64_t> v) { int64_t r = 0; for (auto x : v) r = std::max(r, x); return r; };
+    const int64_t n_f32a = mx({2LL * Tp * H, (int64_t)Lp * Hc, (int64_t)qc * W});
+    const int64_t n_xn = n_f32a;
+    const int64_t n_qkv = mx({2LL * Tp * 3 * H, (int64_t)Nlp * 3 * W, (int64_t)Lp * 3 * Hc, (int64_t)qc * W});
+    const int64_t n_q = mx({2LL * Tp * H, (int64_t)Nlp * W, (int64_t)Lp * Hc, (int64_t)qc * W});
+    const int64_t n_kv = mx({2LL * Tp * H, (int64_t)Nlp * W, (int64_t)Lp * Hc});
+    const int64_t n_cat = mx({2LL * Tp * 5 * H, (int64_t)Nlp * W, (int64_t)Lp * Hc, (int64_t)qc * W});
+    const int64_t n_hid = mx({(int64_t)Nlp * 4 * W, (int64_t)Lp * 3 * m->Fc, (int64_t)qc * c.vae_mlp_ratio * W});
+    const int64_t n_inb = mx({2LL * Nl * m->cin_pad, (int64_t)(qc + 128) * 64, (int64_t)P * P * Kpatch});
+    const int64_t n_small = 2 * 256 + 2 * H + 2 * H + 2 * 12 * H + 4LL * Nl * c.dit_in_channels + 1024;
+    const int64_t n_z = (int64_t)Nl * W;
+    const int64_t n_geo = (int64_t)rup(Nl, 64) * W;
+    size_t off = 0;
+    auto carve = [&](int64_t bytes) { size_t o = off; off += (size_t)rup(bytes, 256); return o; };
+    const size_t o_f32a = carve(n_f32a * 4), o_xn = carve(n_xn * 2), o_qkv = carve(n_qkv * 2), o_q = carve(n_q * 2),
+                 o_k = carve(n_kv * 2), o_vt = carve(n_kv * 2), o_cat = carve(n_cat * 2), o_hid = carve(n_hid * 2),
+                 o_inb = carve(n_inb * 2), o_small = carve(n_small * 4), o_z = carve(n_z * 4), o_gk = carve(n_geo * 2),
+                 o_gv = carve(n_geo * 2);
+    hipError_t e = hipMalloc((void**)&m->arena, off);
+    if (e != hipSuccess) { model_free(m); return hip_fail(e, "hipMalloc(model arena)"); }
+    m->arena_bytes = off;
+    e = hipMemset(m->arena, 0, off);  // padded rows / columns must start finite
+    if (e != hipSuccess) { model_free(m); return hip_fail(e, "hipMemset(model arena)"); }
+    char* a = m->arena;
+    m->f32a = (float*)(a + o_f32a); m->xn = (uint16_t*)(a + o_xn); m->qkv = (uint16_t*)(a + o_qkv);
+    m->Q = (uint16_t*)(a + o_q); m->K = (uint16_t*)(a + o_k); m->Vt = (uint16_t*)(a + o_vt);
+    m->cat = (uint16_t*)(a + o_cat); m->hid = (uint16_t*)(a + o_hid); m->inb = (uint16_t*)(a + o_inb);
+    m->small = (float*)(a + o_small); m->z = (float*)(a + o_z); m->geoK = (uint16_t*)(a + o_gk); m->geoVt = (uint16_t*)(a + o_gv);
+    m->temb = m->small; m->th = m->temb + 2 * 256; m->vec = m->th + 2 * H; m->mods = m->vec + 2 * H;
+    m->v2 = m->mods + 2 * 12 * H;
+    ctx->model = m;
+    return R3G_OK;
+}
+
+}  // namespace r3g
+
+using namespace r3g;
+
+void r3g::Ctx::release_model() {
+    if (model) model_free((Model*)model);
+    model = nullptr;
+}
+
+static Model* model_of(r3g_ctx* ctx) { return ctx ? (Model*)reinterpret_cast<Ctx*>(ctx)->model : nullptr; }
+#define NEED_MODEL(fn)                                                                       \
+    Model* m = model_of(ctx);                                                                \
+    if (!m) return fail(R3G_ERR_STATE, fn ": r3g_model_create has not been called");
+
+extern "C" {
+
+int r3g_model_create(r3g_ctx* ctx, const r3g_model_config* cfg) {
+    if (!ctx || !cfg) return fail(R3G_ERR_INVALID, "r3g_model_create: null argument");
+    return model_create(reinterpret_cast<Ctx*>(ctx), cfg);
+}
+
+int r3g_model_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols) {
+    NEED_MODEL("r3g_model_set_tensor");
+    if (!name || !d_ptr || (dtype != 0 && dtype != 1) || rows <= 0 || cols <= 0)
+        return fail(R3G_ERR_INVALID, "r3g_model_set_tensor: bad argument for '%s'", name ? name : "?");
+    m->w[name] = Tensor{d_ptr, dtype, rows, cols};
+    return R3G_OK;
+}
+
+int r3g_model_set_scalar(r3g_ctx* ctx, const char* name, float value) {
+    NEED_MODEL("r3g_model_set_scalar");
+    if (!name) return fail(R3G_ERR_INVALID, "r3g_model_set_scalar: null name");
+    m->scalars[name] = value;
+    return R3G_OK;
+}
+
+int r3g_cond_encode(r3g_ctx* ctx, const float* d_image, uint16_t* d_cond_out, void* stream) {
+    NEED_MODEL("r3g_cond_encode");
+    if (!d_image || !d_cond_out) return fail(R3G_ERR_INVALID, "r3g_cond_encode: null argument");
+    return cond_encode(*m, d_image, d_cond_out, (hipStream_t)stream);
+}
+
+int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint16_t* d_cond, float* d_out, int batch,
+                    int n_double, int n_single, void* stream) {
+    NEED_MODEL("r3g_dit_forward");
+    if (!d_x || !d_t || !d_cond || !d_out) return fail(R3G_ERR_INVALID, "r3g_dit_forward: null argument");
+    return dit_forward(*m, d_x, d_t, 0.f, d_cond, d_out, batch, n_double, n_single, (hipStream_t)stream);
+}
+
+int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
+                    float shift, void* stream) {
+    NEED_MODEL("r3g_flow_sample");
+    if (!d_latents || !d_cond2 || steps < 1) return fail(R3G_ERR_INVALID, "r3g_flow_sample: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)m->c.vae_num_latents * m->c.dit_in_channels;
+    // sigmas = linspace(0,1,steps) (shifted), + a trailing 1: the last update has d_sigma = 0, as upstream
+    std::vector<float> sig(steps + 1);
+    for (int i = 0; i < steps; ++i) {
+        const double v = steps == 1 ? 0.0 : (double)i / (double)(steps - 1);
+        sig[i] = (float)(shift * v / (1.0 + (shift - 1.0) * v));
+    }
+    sig[steps] = 1.0f;
+    float* x2 = m->v2 + 2 * n;  // [2][n] duplicated latents (CFG batch)
+    for (int i = 0; i < steps; ++i) {
+        R3G_TRY(hipMemcpyAsync(x2, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
+        R3G_TRY(hipMemcpyAsync(x2 + n, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
+        R3G_RC(dit_forward(*m, x2, nullptr, sig[i], d_cond2, m->v2, 2, -1, -1, s));
+        R3G_TRY(cfg_euler_launch(d_latents, m->v2, n, guidance_scale, sig[i + 1] - sig[i], s));
+    }
+    return R3G_OK;
+}
+
+int r3g_vae_decode(r3g_ctx* ctx, const float* d_latents, float* d_z_out, void* stream) {
+    NEED_MODEL("r3g_vae_decode");
+    if (!d_latents) return fail(R3G_ERR_INVALID, "r3g_vae_decode: null argument");
+    R3G_RC(vae_decode(*m, d_latents, (hipStream_t)stream));
+    if (d_z_out)
+        R3G_TRY(hipMemcpyAsync(d_z_out, m->z, (size_t)m->c.vae_num_latents * m->W * 4, hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    return R3G_OK;
+}
+
+int r3g_grid_query(r3g_ctx* ctx, double bound, int octree_resolution, float* d_grid, int64_t start, int64_t count,
+                   void* stream) {
+    NEED_MODEL("r3g_grid_query");
+    if (!d_grid || octree_resolution < 1) return fail(R3G_ERR_INVALID, "r3g_grid_query: bad argument");
+    return grid_query(*m, bound, octree_resolution, d_grid, start, count, (hipStream_t)stream);
+}
+
+// ---- single-op entry points (parity tests call the kernels through the C ABI) ---------------------------
+int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, void* d_c,
+                int64_t ldc, const float* d_gate, int m_, int n_, int k_, int epilogue, int use_lds_dma, void* stream) {
+    GemmArgs p{};
+    p.A = d_a; p.lda = lda; p.W = d_w; p.ldw = ldw; p.bias = d_bias; p.C = d_c; p.ldc = ldc; p.gate = d_gate;
+    p.M = m_; p.N = n_; p.K = k_; p.epi = epilogue;
+    gemm_set_glds(use_lds_dma != 0);
+    hipError_t e = gemm_launch(p, 1, (hipStream_t)stream);
+    gemm_set_glds(true);
+    if (e != hipSuccess) return hip_fail(e, "r3g_op_gemm");
+    return R3G_OK;
+}
+
+int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
+                     int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream) {
+    AttnArgs p{};
+    p.Q = d_q; p.K = d_k; p.Vt = d_vt; p.O = d_o; p.ldo = (int64_t)heads * 64; p.strideO = (int64_t)lq * heads * 64;
+    p.B = batch; p.H = heads; p.Lq = lq; p.Lq_pad = lq_pad; p.Lk = lk; p.Lk_pad = lk_pad;
+    p.kv_batch_stride_zero = shared_kv; p.scale = 0.125f;
+    attn_set_glds(use_lds_dma != 0);
+    hipError_t e = attention_launch(p, (hipStream_t)stream);
+    attn_set_glds(true);
+    if (e != hipSuccess) return hip_fail(e, "r3g_op_attention");
+    return R3G_OK;
+}
+
+int r3g_set_staging(int use_lds_dma) {
+    gemm_set_glds(use_lds_dma != 0);
+    attn_set_glds(use_lds_dma != 0);
+    return R3G_OK;
+}
+
+}  // extern "C"

@@ -26,7 +26,8 @@ struct Ctx {
     bool mc_counted = false;
 
     int reserve(char** buf, size_t* have, size_t need, const char* what);
-    void release_model() {}
+    void* model = nullptr;  // r3g::Model (model.cpp)
+    void release_model();
 };
 
 }  // namespace r3g

@@ -1,0 +1,171 @@
+"""Hunyuan3DDiTFlowMatchingPipeline on MI355X -- same constructor / call surface as upstream
+hy3dgen/shapegen/pipelines.py as used by the reference (src/2d_to_3d_models/run.py:122-124, 77-84):
+
+    pipe = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(path, subfolder=..., variant=...)
+    mesh = pipe(image=pil_rgba, num_inference_steps=50, octree_resolution=256, num_chunks=16000,
+                generator=torch.manual_seed(seed), output_type="trimesh")[0]
+
+All arithmetic runs in libr3g.so (HIP kernels); this file is host plumbing.  `num_chunks` is accepted and
+ignored: the grid query is chunked internally and its result does not depend on the chunk size.
+"""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from r3g import mc as _mc
+from r3g import model as _model
+from r3g import weights as _weights
+from r3g.mesh import Mesh
+
+from .preprocessors import ImageProcessorV2, conditioner_transform
+
+FULL = dict(
+    dit=dict(in_channels=64, context_in_dim=1536, hidden_size=1024, mlp_ratio=4.0, num_heads=16, depth=16,
+             depth_single_blocks=32, qkv_bias=True, time_factor=1000, guidance_embed=False),
+    vae=dict(num_latents=3072, embed_dim=64, width=1024, heads=16, num_decoder_layers=16, num_freqs=8,
+             include_pi=False, qkv_bias=False, qk_norm=True, scale_factor=0.9990943042622529,
+             geo_decoder_mlp_expand_ratio=4, geo_decoder_ln_post=True),
+    cond=dict(image_size=518, patch_size=14, hidden_size=1536, num_hidden_layers=40, num_attention_heads=24,
+              mlp_ratio=4, use_swiglu_ffn=True, layer_norm_eps=1e-6),
+    sched=dict(num_train_timesteps=1000, shift=1.0),
+    proc=dict(size=512, border_ratio=0.15),
+    guidance_scale=5.0, box_v=1.01, mc_level=0.0)
+
+
+def builtin_config(name):
+    """'full' = hunyuan3d-dit-v2-0, 'mini' = hunyuan3d-dit-v2-mini (dims recalled)."""
+    import copy
+    c = copy.deepcopy(FULL)
+    if name == "mini":
+        c["dit"].update(depth=8, depth_single_blocks=16)
+        c["vae"].update(num_latents=512)
+    elif name != "full":
+        raise KeyError(name)
+    return c
+
+
+def config_from_yaml(doc):
+    """upstream config.yaml ({model, vae, conditioner, scheduler, image_processor}.params) -> cfg dict"""
+    import copy
+    c = copy.deepcopy(FULL)
+    mp = doc.get("model", {}).get("params", {})
+    for k in c["dit"]:
+        if k in mp:
+            c["dit"][k] = mp[k]
+    vp = doc.get("vae", {}).get("params", {})
+    for k in c["vae"]:
+        if k in vp:
+            c["vae"][k] = vp[k]
+    enc = doc.get("conditioner", {}).get("params", {}).get("main_image_encoder", {}).get("kwargs", {})
+    for k in c["cond"]:
+        if k in enc.get("config", {}):
+            c["cond"][k] = enc["config"][k]
+    if "image_size" in enc:
+        c["cond"]["image_size"] = enc["image_size"]
+    sp = doc.get("scheduler", {}).get("params", {})
+    c["sched"].update({k: sp[k] for k in ("num_train_timesteps", "shift") if k in sp})
+    ip = doc.get("image_processor", {}).get("params", {})
+    c["proc"].update({k: ip[k] for k in ("size", "border_ratio") if k in ip})
+    return c
+
+
+class Hunyuan3DDiTPipeline:
+    def __init__(self, cfg, state_dict, device="cuda", grid_chunk=0):
+        dev = torch.device(device)
+        self.cfg = cfg
+        self.device = torch.device("cuda", dev.index or 0)
+        self.model = _model.ShapeModel(cfg, state_dict, self.device.index, grid_chunk=grid_chunk)
+        self.image_processor = ImageProcessorV2(**cfg["proc"])
+        self.last_grid = None
+        self.timings = {}
+
+    # ---- construction (same entry points as upstream) -------------------------------------------
+    @classmethod
+    def from_pretrained(cls, model_path, device="cuda", dtype=None, use_safetensors=True, variant="fp16",
+                        subfolder="hunyuan3d-dit-v2-0", **kwargs):
+        """model_path: a local directory holding <subfolder>/config.yaml + model[.variant].safetensors
+        (the HF snapshot layout), or 'synthetic:<full|mini>[:seed]' for seeded synthetic weights."""
+        if isinstance(model_path, str) and model_path.startswith("synthetic:"):
+            parts = model_path.split(":")
+            cfg = builtin_config(parts[1])
+            seed = int(parts[2]) if len(parts) > 2 else 0
+            return cls(cfg, _weights.synthetic_state_dict(cfg, seed, device=device), device, **kwargs)
+        path = os.path.join(os.path.expanduser(model_path), subfolder)
+        if not os.path.isdir(path):
+            raise FileNotFoundError("model directory not found: %s (no network access: pass a local snapshot "
+                                    "directory or 'synthetic:full')" % path)
+        with open(os.path.join(path, "config.yaml")) as f:
+            cfg = config_from_yaml(yaml.safe_load(f))
+        return cls(cfg, _weights.load_safetensors_dir(path, variant), device, **kwargs)
+
+    @classmethod
+    def from_single_file(cls, ckpt_path, config_path, device="cuda", dtype=None, use_safetensors=None, **kwargs):
+        from safetensors.torch import load_file
+        with open(config_path) as f:
+            cfg = config_from_yaml(yaml.safe_load(f))
+        return cls(cfg, load_file(ckpt_path), device, **kwargs)
+
+    def to(self, device=None, dtype=None):
+        return self
+
+    # ---- stages --------------------------------------------------------------------------------------
+    def prepare_image(self, image):
+        if isinstance(image, str) and not os.path.exists(image):
+            raise FileNotFoundError("Couldn't find image at path " + image)
+        return self.image_processor(image)
+
+    def encode_cond(self, image):
+        """conditioner(image) and its unconditional (zeros) twin -> bf16 [2, tokens, dim] = [cond, uncond]"""
+        x = conditioner_transform(image, self.cfg["cond"]["image_size"])[0]
+        cond = self.model.cond_encode(x)
+        return torch.stack([cond, torch.zeros_like(cond)], dim=0)
+
+    def prepare_latents(self, generator):
+        shape = (self.model.num_latents, self.model.in_channels)
+        # diffusers.randn_tensor with a CPU generator: drawn on the CPU, then moved (device independent noise);
+        # drawn in fp32 here (upstream draws in the pipeline dtype, fp16)
+        if generator is not None and generator.device.type != "cpu":
+            return torch.randn(shape, generator=generator, device=generator.device, dtype=torch.float32).to(self.device)
+        return torch.randn(shape, generator=generator, device="cpu", dtype=torch.float32).to(self.device)
+
+    def generate_grid(self, image, num_inference_steps, guidance_scale, generator, box_v, octree_resolution):
+        import time
+        t0 = time.perf_counter()
+        cond_inputs = self.prepare_image(image)
+        cond2 = self.encode_cond(cond_inputs["image"])
+        latents = self.prepare_latents(generator)
+        latents = self.model.flow_sample(latents, cond2, num_inference_steps, guidance_scale,
+                                         self.cfg["sched"].get("shift", 1.0))
+        self.model.vae_decode(latents)
+        grid = self.model.grid_query(box_v, octree_resolution)
+        self.timings["grid_s"] = time.perf_counter() - t0
+        return grid, latents
+
+    @torch.no_grad()
+    def __call__(self, image=None, num_inference_steps=50, timesteps=None, sigmas=None, eta=0.0, guidance_scale=None,
+                 generator=None, box_v=None, octree_resolution=384, mc_level=None, mc_algo=None, num_chunks=8000,
+                 output_type="trimesh", enable_pbar=True, **kwargs):
+        if image is None:
+            raise ValueError("image is required")
+        if mc_algo not in (None, "mc"):
+            raise NotImplementedError("only mc_algo='mc' (Lewiner marching cubes) is on the reference path")
+        g = self.cfg["guidance_scale"] if guidance_scale is None else guidance_scale
+        box_v = self.cfg["box_v"] if box_v is None else box_v
+        mc_level = self.cfg["mc_level"] if mc_level is None else mc_level
+        with torch.cuda.device(self.device):
+            grid, latents = self.generate_grid(image, num_inference_steps, g, generator, box_v, octree_resolution)
+            self.last_grid = grid
+            try:
+                v, f = _mc.extract_mesh(grid, mc_level, box_v, octree_resolution)
+            except (ValueError, RuntimeError) as e:   # upstream: traceback + None for this object
+                print("[hy3dgen] surface extraction failed: %s" % e)
+                return [None]
+            if output_type == "trimesh":
+                return [Mesh(v.cpu().numpy(), f.cpu().numpy())]
+            return [(v, f)]
+
+
+class Hunyuan3DDiTFlowMatchingPipeline(Hunyuan3DDiTPipeline):
+    pass

@@ -36,7 +36,30 @@ SYMBOLS = {
     "r3g_destroy": (None, [_P]),
     "r3g_mc_count": (_I, [_P, _P, _I, _I, _I, _D, _I, _I64P, _I64P, _P]),
     "r3g_mc_emit": (_I, [_P, _P, _P, _P, _I, _P]),
+    "r3g_model_create": (_I, [_P, _P]),
+    "r3g_model_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
+    "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),
+    "r3g_cond_encode": (_I, [_P, _P, _P, _P]),
+    "r3g_dit_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "r3g_flow_sample": (_I, [_P, _P, _P, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "r3g_vae_decode": (_I, [_P, _P, _P, _P]),
+    "r3g_grid_query": (_I, [_P, _D, _I, _P, ctypes.c_int64, ctypes.c_int64, _P]),
+    "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
+    "r3g_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "r3g_set_staging": (_I, [_I]),
 }
+
+
+class ModelConfig(ctypes.Structure):
+    """struct r3g_model_config (include/r3g.h)"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "dit_in_channels", "dit_context_dim", "dit_hidden", "dit_heads", "dit_depth_double", "dit_depth_single",
+        "dit_mlp_hidden", "dit_qkv_bias")] + [("dit_time_factor", ctypes.c_float)] + [(n, ctypes.c_int32) for n in (
+            "vae_num_latents", "vae_embed_dim", "vae_width", "vae_heads", "vae_layers", "vae_num_freqs",
+            "vae_include_pi", "vae_qkv_bias", "vae_qk_norm", "vae_mlp_ratio", "vae_ln_post")] + [
+        ("vae_scale_factor", ctypes.c_float)] + [(n, ctypes.c_int32) for n in (
+            "cond_image_size", "cond_patch", "cond_hidden", "cond_layers", "cond_heads", "cond_ffn_hidden")] + [
+        ("cond_ln_eps", ctypes.c_float), ("grid_chunk", ctypes.c_int32)]
 
 _LIB = None
 _CTX = {}

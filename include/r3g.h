@@ -72,6 +72,78 @@ int r3g_mc_count(r3g_ctx* ctx, const float* d_grid, int n0, int n1, int n2, doub
 int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xform, int reverse_faces,
                 void* stream);
 
+/* ---- shape model (DiT + ShapeVAE + DINOv2 conditioner) -----------------------------------------
+ * Replaces the modules `Hunyuan3DDiTFlowMatchingPipeline.from_pretrained` instantiates from the
+ * checkpoint's config.yaml (reference call sites src/2d_to_3d_models/run.py:122-124,204-206;
+ * upstream hy3dgen/shapegen/pipelines.py).  All dimensions are data; head_dim must be 64.
+ */
+typedef struct r3g_model_config {
+    /* denoisers/hunyuan3ddit.py Hunyuan3DDiT */
+    int32_t dit_in_channels, dit_context_dim, dit_hidden, dit_heads, dit_depth_double, dit_depth_single,
+        dit_mlp_hidden, dit_qkv_bias;
+    float dit_time_factor;
+    /* autoencoders/model.py ShapeVAE (+ geo_decoder) */
+    int32_t vae_num_latents, vae_embed_dim, vae_width, vae_heads, vae_layers, vae_num_freqs, vae_include_pi,
+        vae_qkv_bias, vae_qk_norm, vae_mlp_ratio, vae_ln_post;
+    float vae_scale_factor;
+    /* conditioner.DinoImageEncoder (transformers Dinov2Model, SwiGLU FFN) */
+    int32_t cond_image_size, cond_patch, cond_hidden, cond_layers, cond_heads, cond_ffn_hidden;
+    float cond_ln_eps;
+    /* query points per internal pass of r3g_grid_query (0 = default 131072); NOT upstream's num_chunks:
+     * results do not depend on it */
+    int32_t grid_chunk;
+} r3g_model_config;
+
+/* Allocate the activation arena for this configuration (replaces instantiate_from_config). */
+int r3g_model_create(r3g_ctx* ctx, const r3g_model_config* cfg);
+/* Register one parameter under its upstream state-dict name ("model.double_blocks.0.img_attn.qkv.weight",
+ * "vae.post_kl.bias", "conditioner.main_image_encoder.model.encoder.layer.0.norm1.weight", ...).
+ * dtype 0 = float32, 1 = bfloat16.  Matrices: bf16 [rows=N][cols=K], K zero-padded to a multiple of 64;
+ * vectors: f32.  The memory stays owned by the caller and must outlive the context.
+ * (Replaces load_state_dict of the safetensors checkpoint.) */
+int r3g_model_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols);
+int r3g_model_set_scalar(r3g_ctx* ctx, const char* name, float value);
+
+/* conditioner forward: d_image f32 [3][S][S] already resized/cropped/normalised (ImageEncoder.transform);
+ * d_cond_out bf16 [S/14*S/14+1][cond_hidden] = Dinov2Model(...).last_hidden_state (CLS first). */
+int r3g_cond_encode(r3g_ctx* ctx, const float* d_image, uint16_t* d_cond_out, void* stream);
+
+/* Hunyuan3DDiT.forward(x, t, contexts={'main': cond}): d_x f32 [B][num_latents][in_channels], d_t f32 [B]
+ * (sigma in [0,1]), d_cond bf16 [B][cond_tokens][context_dim] -> d_out f32 like d_x.  B in {1,2}.
+ * n_double / n_single < 0 run every block (>= 0: only the first n, for per-block parity tests). */
+int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint16_t* d_cond, float* d_out, int batch,
+                    int n_double, int n_single, void* stream);
+
+/* The denoising loop of Hunyuan3DDiTFlowMatchingPipeline.__call__ with classifier-free guidance:
+ * sigmas = linspace(0,1,steps) (+ FlowMatchEulerDiscreteScheduler shift), per step
+ *   v = DiT(cat([x]*2), sigma, d_cond2);  v = v_u + g (v_c - v_u);  x += (sigma_next - sigma) v
+ * d_latents f32 [num_latents][in_channels] in/out; d_cond2 bf16 [2][tokens][dim] = [cond, uncond]. */
+int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
+                    float shift, void* stream);
+
+/* ShapeVAE.forward(latents / scale_factor) (post_kl + transformer) and the geo decoder's K/V of the
+ * result (computed once; upstream recomputes them for every chunk).  d_z_out (optional) f32
+ * [num_latents][width] receives the decoded latents. */
+int r3g_vae_decode(r3g_ctx* ctx, const float* d_latents, float* d_z_out, void* stream);
+
+/* VanillaVolumeDecoder: occupancy logits of dense grid points [start, start+count) of the (R+1)^3 grid
+ * (point index = (i*(R+1)+j)*(R+1)+k, coordinates np.linspace(-bound, bound, R+1)) written to
+ * d_grid[start ...], fp32.  Needs a preceding r3g_vae_decode. */
+int r3g_grid_query(r3g_ctx* ctx, double bound, int octree_resolution, float* d_grid, int64_t start, int64_t count,
+                   void* stream);
+
+/* ---- single kernels, for parity tests through the ABI ------------------------------------------ */
+/* C = epilogue(A[m][k] . W[n][k]^T + bias); epilogue: 0 bf16, 1 bf16 gelu(tanh), 2 bf16 gelu(erf),
+ * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
+int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, void* d_c,
+                int64_t ldc, const float* d_gate, int m, int n, int k, int epilogue, int use_lds_dma, void* stream);
+/* softmax(Q K^T / 8) V for head_dim 64: Q bf16 [B][H][lq_pad][64], K bf16 [B][H][lk_pad][64],
+ * Vt bf16 [B][H][64][lk_pad] -> O bf16 [B][lq][H*64]. */
+int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
+                     int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream);
+/* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
+int r3g_set_staging(int use_lds_dma);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""CPU tests of the host-side logic: checkpoint layout vs the oracle's modules, weight re-layout, the Trimesh-like
+mesh + GLB writer, the cleaners, and the restated image preprocessing (product vs oracle)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_checkpoint_layout_matches_restated_modules():
+    from oracle import hy3d_torch as H
+    from r3g import weights as W
+    cfg = H.tiny_config()
+    pipe = H.ShapePipeline(cfg)
+    ref = {}
+    for prefix, mod in (("model.", pipe.model), ("vae.", pipe.vae), ("conditioner.", pipe.conditioner)):
+        for k, p in mod.state_dict().items():
+            ref[prefix + k] = tuple(p.shape)
+    mine = {k: tuple(v) for k, v in W.param_shapes(cfg).items()}
+    assert mine == ref
+    H.load_state_dict(H.ShapePipeline(cfg), W.synthetic_state_dict(cfg, 0, "cpu"))  # strict=True inside
+
+
+def test_full_config_parameter_count_is_the_published_one():
+    from hy3dgen.shapegen.pipelines import builtin_config
+    from r3g import weights as W
+    shapes = W.param_shapes(builtin_config("full"))
+    n_dit = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("model."))
+    assert 1.05e9 < n_dit < 1.15e9       # "1.1B" DiT
+    n_dino = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("conditioner."))
+    assert 1.1e9 < n_dino < 1.2e9        # dinov2-giant
+
+
+def test_weight_relayout():
+    from oracle import hy3d_torch as H
+    from r3g import model as M
+    cfg = H.tiny_config()
+    sd = H.synthetic_state_dict(cfg, 1)
+    w, scalars = M.prepare_weights(sd, "cpu")
+    k = "model.latent_in.weight"
+    assert w[k][0].shape == (128, 64) and w[k][1] == 1                  # K 16 -> 64, zero padded
+    assert torch.equal(w[k][0][:, 16:].float(), torch.zeros(128, 48))
+    q = "conditioner.main_image_encoder.model.encoder.layer.0.attention.attention"
+    fused = w[q + ".qkv.weight"][0].float()
+    assert torch.equal(fused[192:384], sd[q + ".key.weight"].to(torch.bfloat16).float())
+    assert "vae.geo_decoder.output_proj.bias" in scalars
+    c = M.make_config(cfg)
+    assert c.cond_ffn_hidden == 512 and c.dit_mlp_hidden == 512
+
+
+def test_mesh_glb_roundtrip(tmp_path):
+    from r3g.mesh import Mesh, load_glb
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((50, 3)).astype(np.float32)
+    f = rng.integers(0, 50, (80, 3))
+    m = Mesh(v, f)
+    p = tmp_path / "a" / "a.glb"
+    p.parent.mkdir()
+    m.export(str(p))
+    back = load_glb(str(p))
+    assert np.array_equal(back.vertices.astype(np.float32), v) and np.array_equal(back.faces, f)
+    data = p.read_bytes()
+    assert data[:4] == b"glTF" and len(data) % 4 == 0
+
+
+def test_cleaners():
+    from hy3dgen.shapegen import DegenerateFaceRemover, FaceReducer, FloaterRemover
+    from oracle import mc
+    from mc_volumes import golden_volume
+    vol, level = golden_volume("A")
+    v, f = mc.hy3d_mesh(vol, level)
+    from r3g.mesh import Mesh
+    big = Mesh(v, f)
+    # add a floater: one far-away triangle, and a degenerate face
+    m = Mesh(np.concatenate([v, [[5, 5, 5], [5, 5, 5.1], [5, 5.1, 5]]]), np.concatenate([f, [[len(v), len(v) + 1, len(v) + 2]],
+                                                                                        [[0, 0, 1]]]))
+    m2 = DegenerateFaceRemover()(FloaterRemover()(m))
+    assert len(m2.faces) == len(big.faces) and len(m2.vertices) == len(big.vertices)
+    r = FaceReducer()(big, max_facenum=3000)
+    assert 0 < len(r.faces) <= 3000
+    # still roughly the same sphere
+    rad = np.linalg.norm(r.vertices, axis=1)
+    assert abs(rad.mean() - np.linalg.norm(big.vertices, axis=1).mean()) < 0.05
+
+
+def test_preprocess_product_equals_oracle():
+    from PIL import Image
+    from hy3dgen.shapegen.preprocessors import ImageProcessorV2, conditioner_transform
+    from oracle import hy3d_torch as H
+    rng = np.random.default_rng(1)
+    img = np.zeros((120, 90, 4), np.uint8)
+    img[30:100, 20:70, :3] = rng.integers(0, 255, (70, 50, 3))
+    img[30:100, 20:70, 3] = rng.integers(1, 255, (70, 50))
+    pil = Image.fromarray(img, "RGBA")
+    a = ImageProcessorV2(64, 0.15)(pil)
+    b_img, b_mask = H.preprocess_image(pil, 64, 0.15)
+    assert torch.equal(a["image"], b_img) and torch.equal(a["mask"], b_mask)
+    x = conditioner_transform(a["image"], 70)
+    y = H.DinoImageEncoder.transform((b_img + 1) / 2, 70, H.DinoImageEncoder.mean, H.DinoImageEncoder.std)
+    assert torch.allclose(x, y, atol=1e-6)
+    with pytest.raises(ValueError):
+        ImageProcessorV2(64, 0.15)(Image.fromarray(np.zeros((8, 8, 4), np.uint8), "RGBA"))

@@ -1,0 +1,138 @@
+"""GPU parity of the MFMA kernels (through the C ABI) against a plain PyTorch fp32 reference of the same op.
+Stated tolerances (bf16 operands, fp32 accumulate): GEMM rel-L2 <= 5e-3; attention rel-L2 <= 1e-2."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from r3g import ffi
+    ffi.context(0)
+    return torch, ffi.lib(), ffi
+
+
+def rel_l2(a, b):
+    import torch
+    return float(torch.linalg.norm(a.double() - b.double()) / (torch.linalg.norm(b.double()) + 1e-30))
+
+
+def stream(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gelu_ref(torch, x, mode):
+    import torch.nn.functional as F
+    return F.gelu(x, approximate="tanh") if mode == 1 else F.gelu(x)
+
+
+@pytest.mark.parametrize("dma", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (300, 200, 128), (8960, 1024, 1024),
+                                   (1370, 3072, 1024), (77, 64, 5120), (4442, 4096, 1024)])
+def test_gemm_bf16_bias(env, dma, M, N, K):
+    torch, L, ffi = env
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N, None, M, N, K, 0, dma,
+                            stream(torch)))
+    ref = a.float() @ w.float().t() + bias
+    assert torch.isfinite(c.float()).all()
+    assert rel_l2(c.float(), ref) <= 5e-3
+    # asymmetric operands catch a transposed / permuted store: check a few exact positions too
+    idx = torch.randint(0, M, (16,), device="cuda"), torch.randint(0, N, (16,), device="cuda")
+    assert torch.allclose(c.float()[idx], ref[idx], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3, 4])
+def test_gemm_epilogues(env, epi):
+    torch, L, ffi = env
+    M, N, K = 515, 768, 1024
+    g = torch.Generator(device="cuda").manual_seed(epi)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    gate = torch.randn(N, device="cuda", generator=g)
+    lin = a.float() @ w.float().t() + bias
+    if epi in (1, 2):
+        c = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+        ref = gelu_ref(torch, lin, epi)
+    elif epi == 3:
+        c = torch.randn(M, N, device="cuda", generator=g)
+        ref = c + gate * lin
+    else:
+        c = torch.zeros((M, N), device="cuda")
+        ref = lin
+    ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                            gate.data_ptr() if epi == 3 else None, M, N, K, epi, 1, stream(torch)))
+    assert rel_l2(c.float(), ref) <= 5e-3
+
+
+def test_gemm_strided_views(env):
+    """column slab of a wider weight (ldw > K) and of wider activations / outputs (lda, ldc > width)"""
+    torch, L, ffi = env
+    M, N, K = 200, 256, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a_full = torch.randn(M, 5 * K, device="cuda", generator=g).to(torch.bfloat16)
+    w_full = torch.randn(N, 3 * K, device="cuda", generator=g).to(torch.bfloat16)
+    c_full = torch.zeros(M, 2 * N, device="cuda", dtype=torch.bfloat16)
+    a, w, c = a_full[:, K:2 * K], w_full[:, 2 * K:], c_full[:, N:]
+    ffi.check(L.r3g_op_gemm(a.data_ptr(), 5 * K, w.data_ptr(), 3 * K, None, c.data_ptr(), 2 * N, None, M, N, K, 0, 1,
+                            stream(torch)))
+    assert rel_l2(c.float(), a.float() @ w.float().t()) <= 5e-3
+    assert float(c_full[:, :N].abs().max()) == 0.0
+
+
+def _attn_case(torch, B, H, Lq, Lk, shared, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    Bk = 1 if shared else B
+    q = torch.randn(B, H, Lq, 64, device="cuda", generator=g)
+    k = torch.randn(Bk, H, Lk, 64, device="cuda", generator=g)
+    v = torch.randn(Bk, H, Lk, 64, device="cuda", generator=g)
+    lqp, lkp = (Lq + 127) // 128 * 128, (Lk + 63) // 64 * 64
+    Q = torch.full((B, H, lqp, 64), 3.0, device="cuda", dtype=torch.bfloat16)
+    K = torch.full((Bk, H, lkp, 64), 7.0, device="cuda", dtype=torch.bfloat16)     # junk in the padded keys
+    Vt = torch.zeros((Bk, H, 64, lkp), device="cuda", dtype=torch.bfloat16)
+    Q[:, :, :Lq] = q.to(torch.bfloat16)
+    K[:, :, :Lk] = k.to(torch.bfloat16)
+    Vt[:, :, :, :Lk] = v.to(torch.bfloat16).transpose(2, 3)
+    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float().expand(B, -1, -1, -1),
+                                                           Vt[:, :, :, :Lk].float().transpose(2, 3).expand(B, -1, -1, -1))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, H * 64)
+    return Q, K, Vt, ref, lqp, lkp
+
+
+@pytest.mark.parametrize("dma", [1, 0])
+@pytest.mark.parametrize("B,H,Lq,Lk,shared", [(1, 1, 128, 64, 0), (1, 2, 200, 200, 0), (2, 16, 4442, 4442, 0),
+                                              (1, 3, 26, 26, 0), (3, 4, 500, 3072, 1), (1, 24, 1370, 1370, 0)])
+def test_attention(env, dma, B, H, Lq, Lk, shared):
+    torch, L, ffi = env
+    Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, shared, Lq + Lk)
+    o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
+    ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, shared,
+                                 dma, stream(torch)))
+    assert torch.isfinite(o.float()).all()
+    assert rel_l2(o.float(), ref) <= 1e-2
+
+
+def test_attention_forced_rescale(env):
+    """One key row spiked against one query so the running max jumps late in the sequence
+    (exercises the online-softmax rescale branch with a large factor)."""
+    torch, L, ffi = env
+    B, H, Lq, Lk = 1, 1, 128, 512
+    Q, K, Vt, _, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, 0, 11)
+    K[0, 0, 400] = (Q[0, 0, 5].float() * 4).to(torch.bfloat16)
+    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float(),
+                                                           Vt[:, :, :, :Lk].float().transpose(2, 3))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, 64)
+    o = torch.zeros(B, Lq, 64, device="cuda", dtype=torch.bfloat16)
+    ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, 0, 1,
+                                 stream(torch)))
+    assert rel_l2(o.float(), ref) <= 1e-2
+    assert torch.allclose(o.float()[0, 5], Vt[0, 0, :, 400].float(), atol=3e-2)
