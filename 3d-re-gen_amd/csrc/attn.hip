@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "prof.h"
 
 namespace r3g {
 namespace {
@@ -212,6 +213,7 @@ void attn_set_glds(bool on) { g_attn_glds = on; }
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.Lq_pad % 128 || p.Lk_pad % 64 || p.Lk <= 0 || p.Lq <= 0 || p.Lk > p.Lk_pad || p.Lq > p.Lq_pad)
         return hipErrorInvalidValue;
+    ProfScope ps(PC_ATTN, 4.0 * (double)p.B * p.H * p.Lq * p.Lk * 64, s);
     dim3 grid(p.Lq_pad / 128, p.H, p.B);
     if (g_attn_glds) {
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, p);

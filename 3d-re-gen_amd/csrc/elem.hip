@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "prof.h"
 
 namespace r3g {
 namespace {
@@ -364,6 +365,7 @@ inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;
     if (p.C % 64 || p.C > 2048) return hipErrorInvalidValue;
+    ProfScope ps(PC_LAYERNORM, 6.0 * (double)p.rows * p.C, s);
     if (p.C % 256 == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0) {
         hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     } else {
@@ -375,6 +377,7 @@ hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
 hipError_t qkv_split_launch(const QkvSplitArgs& p, hipStream_t s) {
     if (p.L <= 0) return hipSuccess;
     if (p.dst_row0 % 64) return hipErrorInvalidValue;
+    ProfScope ps(PC_QKV_SPLIT, 4.0 * 64.0 * p.L * p.H * p.B * ((p.q_off >= 0) + (p.k_off >= 0) + (p.v_off >= 0)), s);
     hipLaunchKernelGGL(qkv_split_kernel, dim3((p.L + 63) / 64, p.H, p.B), dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -383,6 +386,7 @@ hipError_t gemv_launch(const float* x, int B, int K, const uint16_t* W, int64_t 
                        int N, int act_silu_in, int act_silu_out, hipStream_t s) {
     if (B > 8 || K % 8 || (size_t)B * K * 4 > 64 * 1024) return hipErrorInvalidValue;
     const int blocks = N >= 1024 ? 256 : (N + 3) / 4;
+    ProfScope ps(PC_GEMV, 2.0 * (double)N * K, s);
     hipLaunchKernelGGL(gemv_kernel, dim3(blocks), dim3(256), (size_t)B * K * 4, s, x, B, K, W, ldw, bias, y, N,
                        act_silu_in, act_silu_out);
     return hipGetLastError();
@@ -390,29 +394,34 @@ hipError_t gemv_launch(const float* x, int B, int K, const uint16_t* W, int64_t 
 
 hipError_t timestep_embedding_launch(const float* t, float t_scalar, int B, float time_factor, float* out,
                                      hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(256), 0, s, t, t_scalar, B, time_factor, out);
     return hipGetLastError();
 }
 
 hipError_t cast_pad_launch(const float* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int C, int Cpad,
                            float scale, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks_for((int64_t)rows * Cpad, 256)), dim3(256), 0, s, in, ldi, out, ldo,
                        rows, C, Cpad, scale);
     return hipGetLastError();
 }
 
 hipError_t fill_rows_launch(float* dst, int64_t ld, int rows, int C, const float* vals, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(fill_rows_kernel, dim3(blocks_for((int64_t)rows * C, 256)), dim3(256), 0, s, dst, ld, rows, C, vals);
     return hipGetLastError();
 }
 
 hipError_t cfg_euler_launch(float* latents, const float* v2, int64_t n, float guidance, float dsigma, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, latents, v2, n, guidance, dsigma);
     return hipGetLastError();
 }
 
 hipError_t swiglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s) {
     if (F % 8) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(swiglu_kernel, dim3(blocks_for((int64_t)rows * F / 8, 256)), dim3(256), 0, s, in, ldi, out, ldo,
                        rows, F);
     return hipGetLastError();
@@ -421,6 +430,7 @@ hipError_t swiglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t
 hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, double bound, int num_freqs,
                                int include_pi, hipStream_t s) {
     if (3 + 6 * num_freqs > 64) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(fourier_grid_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, s, out, start, count, R, bound,
                        num_freqs, include_pi);
     return hipGetLastError();
@@ -428,6 +438,7 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
 
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb,
                          float eps, const float* w, float b, float* out, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(ln_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b,
                        out);
     return hipGetLastError();
@@ -435,16 +446,19 @@ hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln
 
 hipError_t im2col_launch(const float* img, int S, int ps, uint16_t* out, int Kpad, hipStream_t s) {
     const int P = S / ps;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for((int64_t)P * P * Kpad, 256)), dim3(256), 0, s, img, S, ps, out, Kpad);
     return hipGetLastError();
 }
 
 hipError_t add_rows_launch(float* x, int64_t ldx, const float* pos, int64_t ldp, int rows, int C, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(add_rows_kernel, dim3(blocks_for((int64_t)rows * C, 256)), dim3(256), 0, s, x, ldx, pos, ldp, rows, C);
     return hipGetLastError();
 }
 
 hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, out, n);
     return hipGetLastError();
 }

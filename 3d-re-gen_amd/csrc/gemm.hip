@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "prof.h"
 
 namespace r3g {
 namespace {
@@ -215,6 +216,7 @@ hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) {
     if (!attr_done) {
         attr_done = true;  // 64 KiB dynamic LDS is within the default limit on gfx950; nothing to raise
     }
+    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, batch, g_gemm_glds, s);
         case EPI_BF16_GELU_TANH: return launch_epi<EPI_BF16_GELU_TANH>(p, batch, g_gemm_glds, s);

@@ -22,6 +22,7 @@
 #define R3G_LUT_QUAL static __device__ const
 #include "mc_cell.h"
 #include "mc_kernels.h"
+#include "prof.h"
 
 #pragma clang fp contract(off)
 
@@ -214,8 +215,12 @@ hipError_t mc_count_launch(const float* grid, int n0, int n1, int n2, double lev
     unsigned* status = (unsigned*)(ws + lay.off_small);
     unsigned long long* totals = (unsigned long long*)(ws + lay.off_small + 16);
     unsigned long long* chunk_sums = (unsigned long long*)(ws + lay.off_small + 32);
+    {
+    ProfScope ps(PC_MC_CLASSIFY, 4.0 * (double)n0 * n1 * n2, stream);
     hipLaunchKernelGGL(mc_classify, dim3(lay.nblk), dim3(kBlock), 0, stream, grid, nx, ny, cx, cy, lay.ncells, level,
                        classic, (uint2*)(ws + lay.off_act), (uint4*)(ws + lay.off_blk), chunk_sums, status);
+    }
+    ProfScope ps2(PC_MC_OTHER, 0.0, stream);
     hipLaunchKernelGGL(mc_scan, dim3(lay.nchunk), dim3(kChunk), 0, stream, (const uint4*)(ws + lay.off_blk), lay.nblk,
                        chunk_sums, (uint2*)(ws + lay.off_blkoff), totals);
     return hipGetLastError();
@@ -232,6 +237,7 @@ hipError_t mc_emit_launch(const float* grid, int n0, int n1, int n2, double leve
         xf.bbox_size[i] = xf9 ? xf9[3 + i] : 1.0;
         xf.bbox_min[i] = xf9 ? xf9[6 + i] : 0.0;
     }
+    ProfScope ps(PC_MC_OTHER, 0.0, stream);
     hipLaunchKernelGGL(mc_vertices, dim3(lay.nblk), dim3(kBlock), 0, stream, grid, nx, ny, cx, cy, level,
                        (const uint2*)(ws + lay.off_act), (const uint4*)(ws + lay.off_blk),
                        (const uint2*)(ws + lay.off_blkoff), (int32_t*)(ws + lay.off_etab), verts, xf, xf9 ? 1 : 0);

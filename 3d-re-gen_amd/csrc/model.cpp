@@ -25,6 +25,7 @@
 
 #include "../../include/r3g.h"
 #include "kernels.h"
+#include "prof.h"
 #include "r3g_ctx.h"
 
 namespace r3g {
@@ -620,6 +621,19 @@ int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d
     hipError_t e = attention_launch(p, (hipStream_t)stream);
     attn_set_glds(true);
     if (e != hipSuccess) return hip_fail(e, "r3g_op_attention");
+    return R3G_OK;
+}
+
+int r3g_prof_enable(int on) {
+    prof_enable(on != 0);
+    return R3G_OK;
+}
+
+int r3g_prof_read(int64_t* counts, double* ms, double* work, int n) {
+    if (!counts || !ms || !work || n < PC_COUNT) return fail(R3G_ERR_INVALID, "r3g_prof_read: need %d slots", (int)PC_COUNT);
+    long long c[PC_COUNT];
+    prof_read(c, ms, work);
+    for (int i = 0; i < PC_COUNT; ++i) counts[i] = c[i];
     return R3G_OK;
 }
 

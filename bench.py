@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- objects/sec of the Hunyuan_2d_to_3d hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps 8 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE object: a synthetic 512x512 RGBA crop (host PIL image, as the segmentation stage hands it over)
+-> preprocess -> DINOv2-g conditioner -> 50-step flow-matching DiT with CFG (batch 2) -> shape-VAE decode ->
+dense 257^3 occupancy-grid query -> Lewiner marching cubes, mesh left in HBM.  Model load, mesh cleaners,
+texture generation and GLB export are outside the metric.  Workload at N=1 = BASELINE.json
+configs[1] ("1 scene / 8 object crops, Hunyuan3D-2 base bf16, 50 steps, 256^3 grid"): the default --steps 8 is
+one scene.  Weights are seeded synthetic (no checkpoint / network here); the arithmetic is the full model's.
+
+At N > 1 every rank processes its own K objects (object-parallel, no data-path collective; the reference uses a
+process pool and the filesystem, src/2d_to_3d_models/run.py:176-193): value = N*K / max-over-ranks time,
+"scaling": "weak".
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel family (bf16 MFMA GEMM), timed live with HIP events on the launch stream
+                 over one further object: achieved = sum of algorithmic FLOPs / sum of launch durations
+  cpu_baseline : the PyTorch-CPU fp32 oracle + the C marching-cubes oracle timed on this box's host cores on a
+                 bounded sample of the same workload and extrapolated (rank 0, N=1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "3d-re-gen_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
+FAMILIES = ["gemm", "attention", "layernorm", "qkv_split", "gemv", "elementwise", "mc_classify", "mc_other"]
+
+
+def synthetic_crop(i, size=512):
+    """SURVEY.md 8d synthetic crop i: seeded alpha blob (35-65 % coverage) + smooth colour noise on white."""
+    from PIL import Image, ImageDraw, ImageFilter
+    rng = np.random.default_rng(1000 + i)
+    alpha = Image.new("L", (size, size), 0)
+    draw = ImageDraw.Draw(alpha)
+    for _ in range(int(rng.integers(3, 7))):
+        cx, cy = rng.uniform(0.3, 0.7, 2) * size
+        w, h = rng.uniform(0.35, 0.65, 2) * size
+        box = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2]
+        if rng.random() < 0.5:
+            draw.ellipse(box, fill=255)
+        else:
+            draw.rounded_rectangle(box, radius=float(rng.uniform(5, 40)), fill=255)
+    alpha = alpha.filter(ImageFilter.GaussianBlur(2))
+    low = (rng.uniform(0, 255, (8, 8, 3))).astype(np.uint8)
+    rgb = np.asarray(Image.fromarray(low, "RGB").resize((size, size), Image.BILINEAR)).copy()
+    a = np.asarray(alpha)
+    rgb[a == 0] = 255
+    return Image.fromarray(np.dstack([rgb, a]), "RGBA")
+
+
+def flops_per_object(cfg, steps, R):
+    """SURVEY.md 8d formulae (K/V projection of the geo decoder counted once)."""
+    d, v = cfg["dit"], cfg["vae"]
+    H, m = d["hidden_size"], d["mlp_ratio"]
+    Lc = (cfg["cond"]["image_size"] // cfg["cond"]["patch_size"]) ** 2 + 1
+    T = v["num_latents"] + Lc
+    dbl = 2 * T * (3 * H * H + H * H + 2 * m * H * H) + 4 * T * T * H
+    sgl = 2 * T * (H * (3 * H + m * H) + (H + m * H) * H) + 4 * T * T * H
+    f_dit = d["depth"] * dbl + d["depth_single_blocks"] * sgl
+    W, N = v["width"], v["num_latents"]
+    f_vae = v["num_decoder_layers"] * (2 * N * (3 * W * W + W * W + 8 * W * W) + 4 * N * N * W)
+    f_q = 2 * (51 * W + 2 * W * W + 2 * 4 * W * W + W) + 4 * N * W
+    return 2 * steps * f_dit + f_vae + (R + 1) ** 3 * f_q
+
+
+def cpu_baseline(cfg, steps, R, grid_np):
+    """Oracle (PyTorch CPU fp32 restatement + C marching cubes) on a bounded sample, extrapolated to one object."""
+    from oracle import hy3d_torch as H
+    from oracle import mc as omc
+    torch.manual_seed(0)
+    wide = H.wide_config(depth=1, depth_single=1, vae_layers=1, cond_layers=1)
+    pipe = H.ShapePipeline(wide)
+    d, v = cfg["dit"], cfg["vae"]
+    Lc = (cfg["cond"]["image_size"] // cfg["cond"]["patch_size"]) ** 2 + 1
+    x = torch.randn(2, v["num_latents"], d["in_channels"])
+    cond = torch.randn(2, Lc, d["context_in_dim"])
+    t = torch.tensor([0.5, 0.5])
+
+    spent = [0.0]
+
+    def tm(fn, reps=3):
+        best = float("inf")
+        for _ in range(reps):   # min of 3: the first call pays allocator / thread-pool warm-up
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                fn()
+            dt_ = time.perf_counter() - t0
+            spent[0] += dt_
+            best = min(best, dt_)
+        return best
+    t_io = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=0))
+    t_d = tm(lambda: pipe.model(x, t, cond, n_double=1, n_single=0)) - t_io
+    t_s = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=1)) - t_io
+    lat = torch.randn(1, v["num_latents"], v["embed_dim"])
+    z = [None]
+    t_vae = tm(lambda: z.__setitem__(0, pipe.vae(lat)))
+    img = torch.randn(1, 3, cfg["cond"]["image_size"], cfg["cond"]["image_size"])
+    t_cond = tm(lambda: pipe.conditioner.main_image_encoder.model(img))
+    chunk = 16000  # reference num_chunks_hy, src/config.yaml:169
+    pts = torch.from_numpy(H.dense_grid_points(1.01, R)[:chunk])[None]
+    t_chunk = tm(lambda: pipe.vae.geo_decoder(queries=pts, latents=z[0]))
+    t0 = time.perf_counter()
+    try:
+        omc.hy3d_mesh(grid_np, 0.0, 1.01, R)
+    except (ValueError, RuntimeError):
+        pass
+    t_mc = time.perf_counter() - t0
+    n_chunks = -(-((R + 1) ** 3) // chunk)
+    t_obj = (steps * (d["depth"] * t_d + d["depth_single_blocks"] * t_s + t_io) + v["num_decoder_layers"] * t_vae +
+             cfg["cond"]["num_hidden_layers"] * t_cond + n_chunks * t_chunk + t_mc)
+    measured = spent[0] + t_mc
+    return {"value": 1.0 / t_obj, "unit": "objects/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "extrapolated": True, "seconds_per_object": t_obj, "cpu_seconds_measured": measured,
+            "sample": "fp32 oracle at full widths: 1 double + 1 single DiT block (CFG batch 2, 4442 tokens), 1 VAE layer, "
+                      "1 DINOv2-g layer, 1 chunk of 16000 grid queries, C marching cubes on the full %d^3 grid; "
+                      "extrapolated x(%d steps x 16/32 blocks), x16 VAE, x40 DINO, x%d chunks" % (R + 1, steps, n_chunks)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="full", choices=["full", "mini"])
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--octree-resolution", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
+    from r3g import ffi
+    pipe = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("synthetic:%s:0" % a.model, device="cuda:%d" % local)
+    cfg = pipe.cfg
+    S, R = a.inference_steps, a.octree_resolution
+    n_local = a.warmup + a.steps + 1
+    crops = [synthetic_crop(rank + world * j) for j in range(n_local)]   # host PIL images (the stage's input format)
+
+    def one(img):
+        return pipe(image=img, num_inference_steps=S, octree_resolution=R, num_chunks=16000,
+                    generator=torch.manual_seed(1234567), output_type="raw")[0]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for j in range(a.warmup):
+        one(crops[j])
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for j in range(a.steps):
+        last = one(crops[a.warmup + j])
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = None
+    if rank == 0:
+        total = world * a.steps
+        out = {"metric": "objects/sec (50-step Hunyuan3D-2 DiT + 256^3 marching cubes)", "value": total / dt,
+               "unit": "objects/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "configs[1]: %d synthetic 512x512 RGBA crops per GPU, Hunyuan3D-2 %s dims bf16, "
+                                      "%d flow-matching steps x CFG 2, %d^3 grid query + Lewiner marching cubes"
+                                      % (a.steps, a.model, S, R + 1),
+                          "weights": "seeded synthetic", "objects_total": total,
+                          "parallelism": "object-parallel x%d" % world},
+               "flops_per_object": flops_per_object(cfg, S, R),
+               "mesh_last": None if last is None else {"V": int(last[0].shape[0]), "F": int(last[1].shape[0])}}
+        out["mfma_utilisation_end_to_end"] = out["flops_per_object"] * out["value"] / world / (PEAK_BF16_TFLOPS * 1e12)
+
+    if rank == 0 and not a.no_roofline:
+        L = ffi.lib()
+        ffi.check(L.r3g_prof_enable(1))
+        one(crops[a.warmup + a.steps])
+        torch.cuda.synchronize()
+        n = len(FAMILIES)
+        cnt, ms, work = (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        ffi.check(L.r3g_prof_read(cnt, ms, work, n))
+        ffi.check(L.r3g_prof_enable(0))
+        fam = {FAMILIES[i]: {"launches": int(cnt[i]), "ms": float(ms[i]), "work": float(work[i])} for i in range(n)}
+        dom = max(("gemm", "attention"), key=lambda k: fam[k]["ms"])
+        ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12 if fam[dom]["ms"] > 0 else 0.0
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches": fam[dom]["launches"],
+                           "avg_launch_us": 1000.0 * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
+                           "families_ms_per_object": {k: round(v["ms"], 3) for k, v in fam.items()},
+                           "attention_tflops": (fam["attention"]["work"] / (fam["attention"]["ms"] * 1e-3) / 1e12
+                                                if fam["attention"]["ms"] > 0 else 0.0),
+                           "mc_classify_gbps": (fam["mc_classify"]["work"] / (fam["mc_classify"]["ms"] * 1e-3) / 1e9
+                                                if fam["mc_classify"]["ms"] > 0 else 0.0)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, S, R, pipe.last_grid.cpu().numpy())
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,11 @@ int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t l
  * Vt bf16 [B][H][64][lk_pad] -> O bf16 [B][lq][H*64]. */
 int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
                      int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream);
+/* Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).  Families, in order:
+ * 0 gemm, 1 attention, 2 layernorm, 3 qkv_split, 4 gemv, 5 elementwise, 6 mc_classify, 7 mc_other (n >= 8).
+ * work = algorithmic FLOPs (0,1,4) / bytes (6) summed over the launches since r3g_prof_enable(1). */
+int r3g_prof_enable(int on);
+int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);
 
