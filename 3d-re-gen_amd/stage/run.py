@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference stage script src/2d_to_3d_models/run.py (pipeline name "Hunyuan_2d_to_3d").
+
+Same CLI (`--config <yaml>`), same YAML keys (src/config.yaml: mini, num_inf_steps_hy, octree_resolution_hy,
+num_chunks_hy, seed, remesh, remesh_target_num_faces, input_folder_hy, output_folder_hy, use_banana,
+prepped_for_hunyuan, jobs_per_gpu, use_all_available_cuda), same filesystem contract (reference :160-173, :99-102):
+every *.png/*.jpg/*.jpeg of the input folder except names containing wall/walls/room/ceiling/floor; the output
+folder is created and emptied; one `<out>/<stem>/<stem>.glb` per image; FileNotFoundError without images.
+
+What differs, by design (MI355X-first):
+  * one persistent process per GPU (torch.distributed over RCCL; the reference spawns one process per IMAGE and
+    reloads both pipelines each time, :119-130) -- the model is loaded once per rank;
+  * crops are taken round-robin from the SORTED file list (the reference's os.listdir order is filesystem dependent);
+  * per-object failures are collected into a status list and printed (the reference's pool path swallows them,
+    :135-136); the exit code follows the reference: 0 when the stage ran, non-zero only on setup errors
+    (no images / no weights), or when the sequential path hits an exception (as in the reference, :212-213);
+  * weights: private key `r3g_weights` (or env R3G_WEIGHTS) = local snapshot directory or 'synthetic:<full|mini>';
+    without it the HF cache is consulted offline, as there is no network on the target machines.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+IMAGE_EXTENSIONS = (".png", ".jpg", ".jpeg")
+DONT_MESH = ["wall", "walls", "room", "ceiling", "floor"]
+
+
+def load_config(path):
+    """src/utils/global_utils.py:464-476"""
+    import yaml
+    if not os.path.exists(path):
+        raise FileNotFoundError("Config file not found: %s" % path)
+    with open(path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def clear_output_directory(output_dir):
+    """src/utils/global_utils.py:443-461"""
+    if not os.path.exists(output_dir):
+        raise FileNotFoundError("Output directory does not exist: %s" % output_dir)
+    for item in os.listdir(output_dir):
+        p = os.path.join(output_dir, item)
+        if os.path.isdir(p):
+            shutil.rmtree(p)
+        else:
+            os.remove(p)
+
+
+def list_images(input_folder):
+    names = sorted(f for f in os.listdir(input_folder)
+                   if f.lower().endswith(IMAGE_EXTENSIONS) and not any(x in f.lower() for x in DONT_MESH))
+    if not names:
+        raise FileNotFoundError("No images found in the input folder '%s'." % input_folder)
+    return [os.path.join(input_folder, f) for f in names]
+
+
+def select_model(config):
+    """reference :146-157 -- model ids / from_pretrained kwargs, plus the local weights override"""
+    models = {"full": {"id": "tencent/Hunyuan3D-2", "args": {}},
+              "mini": {"id": "tencent/Hunyuan3D-2mini", "args": {"subfolder": "hunyuan3d-dit-v2-mini", "variant": "fp16"}}}
+    key = "mini" if config.get("mini", True) else "full"
+    return key, models[key]
+
+
+def resolve_weights(config, key, model):
+    w = config.get("r3g_weights") or os.environ.get("R3G_WEIGHTS")
+    if w:
+        return w.replace("{model}", key)
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(repo_id=model["id"], local_files_only=True)
+    except Exception as e:
+        raise FileNotFoundError("no local weights for %s: set `r3g_weights:` in the config (a snapshot directory or "
+                                "'synthetic:%s') -- there is no network here (%s)" % (model["id"], key, e))
+
+
+def default_factory(config, device):
+    """-> (pipeline_shapegen, pipeline_texgen, cleaners) using the MI355X hy3dgen mirror"""
+    from hy3dgen.shapegen import (DegenerateFaceRemover, FaceReducer, FloaterRemover,
+                                  Hunyuan3DDiTFlowMatchingPipeline)
+    from hy3dgen.texgen import Hunyuan3DPaintPipeline
+    key, model = select_model(config)
+    print("Using '%s' shape generator: %s" % (key, model["id"]))
+    path = resolve_weights(config, key, model)
+    shapegen = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(path, device=device, **model["args"])
+    texgen = Hunyuan3DPaintPipeline.from_pretrained(path)
+    return shapegen, texgen, [FloaterRemover(), DegenerateFaceRemover(), FaceReducer()]
+
+
+def clean_and_validate_mesh(mesh, min_faces=10, target_face_count=None):
+    """reference clean_and_validate_trimesh :24-64 on the Trimesh-like r3g.mesh.Mesh"""
+    import numpy as np
+    from hy3dgen.shapegen import FaceReducer
+    if mesh is None or mesh.is_empty:
+        raise ValueError("Input is not a valid or is an empty trimesh object.")
+    ok = np.all(np.isfinite(mesh.vertices), axis=1)
+    if not ok.all():
+        print("[WARN] Found %d invalid (NaN/Inf) vertices. Cleaning..." % int((~ok).sum()))
+        mesh.update_vertices(ok)
+    if target_face_count is not None and len(mesh.faces) > target_face_count:
+        mesh = FaceReducer()(mesh, max_facenum=target_face_count)
+    if mesh.is_empty or len(mesh.faces) < min_faces:
+        raise ValueError("Mesh is empty or has fewer than %d faces after cleaning/simplification." % min_faces)
+    mesh.process(validate=True)
+    mesh.remove_unreferenced_vertices()
+    mesh.update_faces(mesh.nondegenerate_faces())
+    if mesh.is_empty or len(mesh.faces) < min_faces:
+        raise ValueError("Mesh became empty after final processing.")
+    return mesh
+
+
+def process_image(image_path, shapegen, texgen, cleaners, output_dir, config):
+    """reference process_image :67-105"""
+    import torch
+    from PIL import Image
+    image = Image.open(image_path).convert("RGBA")
+    base = os.path.splitext(os.path.basename(image_path))[0]
+    print("Processing %s..." % base)
+    t0 = time.time()
+    mesh = shapegen(image=image, num_inference_steps=config.get("num_inf_steps_hy", 100),
+                    octree_resolution=config.get("octree_resolution_hy", 380), num_chunks=config.get("num_chunks_hy", 20000),
+                    generator=torch.manual_seed(config.get("seed", 12345)), output_type="trimesh")[0]
+    if mesh is None:
+        raise RuntimeError("surface extraction produced no mesh")
+    if config.get("remesh", False):
+        mesh = clean_and_validate_mesh(mesh, target_face_count=config.get("remesh_target_num_faces", 30000))
+    print("Initial mesh has %d vertices and %d faces." % (len(mesh.vertices), len(mesh.faces)))
+    for cleaner in cleaners:
+        mesh = cleaner(mesh)
+    print("Cleaned mesh has %d vertices and %d faces." % (len(mesh.vertices), len(mesh.faces)))
+    mesh = texgen(mesh, image=image)
+    out_dir = os.path.join(output_dir, base)
+    os.makedirs(out_dir, exist_ok=True)
+    out_path = os.path.join(out_dir, base + ".glb")
+    mesh.export(out_path)
+    print("Saved %s to %s in %.2f seconds." % (base, out_path, time.time() - t0))
+    return out_path
+
+
+def partition(n_items, rank, world):
+    """static round-robin over the sorted list (reference: i % num_devices, :188-191)"""
+    return list(range(rank, n_items, world))
+
+
+def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_errors):
+    """One persistent rank: load the model once, process its share, return [(index, path, status, seconds)]."""
+    import torch
+    device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu"
+    shapegen, texgen, cleaners = factory(config, device)
+    results = []
+    for i in partition(len(image_paths), rank, world):
+        t0 = time.time()
+        try:
+            process_image(image_paths[i], shapegen, texgen, cleaners, output_folder, config)
+            results.append((i, image_paths[i], "ok", time.time() - t0))
+        except Exception as e:
+            if not swallow_errors:
+                raise
+            print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
+            results.append((i, image_paths[i], "error: %s" % e, time.time() - t0))
+    return results
+
+
+def main(argv=None, factory=default_factory):
+    ap = argparse.ArgumentParser(description="Run 2D to 3D model generation (MI355X-native).")
+    ap.add_argument("--config", default="../src/config.yaml", type=str, help="Path to the configuration file.")
+    args = ap.parse_args(argv)
+    config = load_config(args.config)
+    input_folder = config["input_folder_hy"]
+    if config["use_banana"]:
+        input_folder = config["prepped_for_hunyuan"]
+    output_folder = config["output_folder_hy"]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    import torch
+    if world == 1:
+        os.makedirs(output_folder, exist_ok=True)
+        clear_output_directory(output_folder)
+        image_paths = list_images(input_folder)
+        n_dev = torch.cuda.device_count()
+        slots = n_dev * max(1, int(config.get("jobs_per_gpu", 1)))
+        if n_dev > 1 and len(image_paths) > 1 and slots > 1 and factory is default_factory:
+            # re-launch as one persistent rank per GPU (torch.distributed over RCCL)
+            n = min(n_dev, len(image_paths))
+            print("Found %d GPU(s): launching %d persistent rank(s)." % (n_dev, n))
+            env = dict(os.environ, R3G_STAGE_PREPARED="1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                   "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+                   os.path.abspath(__file__), "--config", args.config]
+            return subprocess.run(cmd, env=env, check=True).returncode
+        print("Running sequentially (%s)." % ("no GPU found" if n_dev == 0 else "only 1 slot or only 1 image"))
+        results = run_rank(config, image_paths, output_folder, 0, 1, factory, swallow_errors=False)
+        report(results)
+        return 0
+
+    # ---- distributed: rank 0 prepares the output folder, everybody waits, then object-parallel work
+    import torch.distributed as dist
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
+    try:
+        if rank == 0 and not os.environ.get("R3G_STAGE_PREPARED"):
+            os.makedirs(output_folder, exist_ok=True)
+            clear_output_directory(output_folder)
+        dist.barrier()
+        image_paths = list_images(input_folder)
+        mine = run_rank(config, image_paths, output_folder, rank, world, factory, swallow_errors=True)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)   # tiny status list; the meshes themselves went to the filesystem
+        if rank == 0:
+            report(sorted(r for part in gathered for r in part))
+            print("All parallel tasks completed.")
+    finally:
+        dist.destroy_process_group()
+    return 0
+
+
+def report(results):
+    ok = sum(1 for r in results if r[2] == "ok")
+    print(json.dumps({"stage": "Hunyuan_2d_to_3d", "objects": len(results), "ok": ok,
+                      "failed": [os.path.basename(r[1]) for r in results if r[2] != "ok"],
+                      "seconds": [round(r[3], 3) for r in results]}))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
