@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "prof.h"
 
@@ -31,11 +33,14 @@ constexpr int KV_TILE = 64;
 constexpr int TILE_B = KV_TILE * 64 * 2;  // 8 KiB: K tile [64 keys][64 d] or V^T tile [64 d][64 keys]
 constexpr int STAGE_B = 2 * TILE_B;
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// v_cvt_pk_bf16_f32 (round to nearest even)
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7FFFu + ((ua >> 16) & 1u);
-    ub += 0x7FFFu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xFFFF0000u);
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&h);
 }
 
 template <bool GLDS>
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](auto masked, const int t) {
         const char* cur = smem + (t & 1) * STAGE_B;
         if (t + 1 < ntiles) stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
 
@@ -133,40 +138,44 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax (log2 domain); reg r of block kb <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
-        const int key_base = t * KV_TILE + 4 * hh;
-        const bool tail = (t + 1) * KV_TILE > p.Lk;
-        float mloc = -INFINITY;
+        // ---- online softmax on the raw scores (scale folded into the exp2 argument);
+        //      reg r of block kb <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh.  Only the last tile can hold padded keys.
+        if constexpr (decltype(masked)::value) {
+            const int key_base = t * KV_TILE + 4 * hh;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key_base + kb * 32 + (r & 3) + 8 * (r >> 2) >= p.Lk) s[kb][r] = -INFINITY;
+        }
+        float mloc = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kb][r] * sc;
-                if (tail) {
-                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= p.Lk) v = -INFINITY;
-                }
-                s[kb][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        // rescale only when some query's running max actually grows (wave-uniform branch; exact, not a threshold)
+        if (__any(mloc > m_run)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mb = m_run * sc;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[kb][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -mb));
                 s[kb][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -187,7 +196,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
+    };
+    const bool pad_tail = ntiles * KV_TILE > p.Lk;
+    for (int t = 0; t < ntiles - 1; ++t) tile(std::false_type{}, t);
+    if (pad_tail) tile(std::true_type{}, ntiles - 1);
+    else tile(std::false_type{}, ntiles - 1);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;

@@ -16,10 +16,9 @@
 namespace r3g {
 namespace {
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) {  // v_cvt_pk_bf16_f32, round to nearest even
+    const __bf16 h = (__bf16)f;
+    return *reinterpret_cast<const uint16_t*>(&h);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -230,6 +229,42 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
     }
 }
 
+// grid (64, njobs): block (bx, job) computes rows bx*4+wave, +256, ... of job's matrix for all B inputs
+__global__ __launch_bounds__(256) void gemv_multi_kernel(const float* __restrict__ x, int B, int K,
+                                                         const GemvJob* __restrict__ jobs, float* __restrict__ y,
+                                                         int silu_in) {
+    extern __shared__ float xs[];
+    for (int i = threadIdx.x; i < B * K; i += 256) {
+        const float v = x[i];
+        xs[i] = silu_in ? silu(v) : v;
+    }
+    __syncthreads();
+    const GemvJob job = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    float* out = y + job.out_off;
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < job.N; n += gridDim.x * 4) {
+        float acc[2] = {0.f, 0.f};
+        const uint16_t* w = job.W + (int64_t)n * job.ldw;
+        for (int k = lane * 8; k < K; k += 512) {
+            const uint4 pk = *reinterpret_cast<const uint4*>(w + k);
+            const uint32_t u[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w0 = __uint_as_float(u[e] << 16), w1 = __uint_as_float(u[e] & 0xFFFF0000u);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (b < B) acc[b] += w0 * xs[b * K + k + 2 * e] + w1 * xs[b * K + k + 2 * e + 1];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (b < B) {
+                const float v = wave_sum(acc[b]);
+                if (lane == 0) out[(int64_t)b * job.N + n] = v + (job.bias ? job.bias[n] : 0.f);
+            }
+    }
+}
+
 __global__ void timestep_embedding_kernel(const float* t, float t_scalar, int B, float time_factor, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 256) return;
@@ -310,6 +345,52 @@ __global__ void fourier_grid_kernel(uint16_t* out, int64_t start, int count, int
 __global__ __launch_bounds__(256) void ln_dot_kernel(const float* x, int64_t ldx, int rows, int C, int do_ln,
                                                      const float* lnw, const float* lnb, float eps, const float* w,
                                                      float b, float* out) {
+    // one wave per row, the row held in registers (C % 256 == 0, C <= 2048): one HBM pass
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const int nv = C >> 8;
+    float4 v[LN_MAX_V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+    float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (!do_ln) { mean = 0.f; rstd = 1.f; }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+            if (do_ln && lnw) {
+                const float4 g = *reinterpret_cast<const float4*>(lnw + c);
+                const float4 h = *reinterpret_cast<const float4*>(lnb + c);
+                o[0] = o[0] * g.x + h.x; o[1] = o[1] * g.y + h.y; o[2] = o[2] * g.z + h.z; o[3] = o[3] * g.w + h.w;
+            }
+            const float4 ww = *reinterpret_cast<const float4*>(w + c);
+            acc += o[0] * ww.x + o[1] * ww.y + o[2] * ww.z + o[3] * ww.w;
+        }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc + b;
+}
+
+// generic-C fallback (C % 64 == 0)
+__global__ __launch_bounds__(256) void ln_dot_small_kernel(const float* x, int64_t ldx, int rows, int C, int do_ln,
+                                                           const float* lnw, const float* lnb, float eps,
+                                                           const float* w, float b, float* out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -392,6 +473,14 @@ hipError_t gemv_launch(const float* x, int B, int K, const uint16_t* W, int64_t 
     return hipGetLastError();
 }
 
+hipError_t gemv_multi_launch(const float* x, int B, int K, const GemvJob* d_jobs, int njobs, float* y, int silu_in,
+                             hipStream_t s) {
+    if (B > 2 || K % 8 || njobs <= 0) return hipErrorInvalidValue;
+    ProfScope ps(PC_GEMV, 0.0, s);
+    hipLaunchKernelGGL(gemv_multi_kernel, dim3(64, njobs), dim3(256), (size_t)B * K * 4, s, x, B, K, d_jobs, y, silu_in);
+    return hipGetLastError();
+}
+
 hipError_t timestep_embedding_launch(const float* t, float t_scalar, int B, float time_factor, float* out,
                                      hipStream_t s) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
@@ -439,8 +528,13 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb,
                          float eps, const float* w, float b, float* out, hipStream_t s) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
-    hipLaunchKernelGGL(ln_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b,
-                       out);
+    if (C % 256 == 0 && C <= 2048 && (ldx & 3) == 0) {
+        hipLaunchKernelGGL(ln_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w,
+                           b, out);
+    } else {
+        hipLaunchKernelGGL(ln_dot_small_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb,
+                           eps, w, b, out);
+    }
     return hipGetLastError();
 }
 

@@ -41,12 +41,22 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (1.0f + th);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// exact-form GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// v_cvt_pk_bf16_f32 (round to nearest even)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&h);
 }
 
 template <bool GLDS>
@@ -150,6 +160,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_QKV) {
+        // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
+        // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
+        const QkvEpi& e = p.qkv;
+        const int g = (n0 + wc * 64) >> 6;
+        if (n0 + wc * 64 >= p.N) return;
+        int type, head;  // 0 q, 1 k, 2 v
+        if (e.layout == QKV_KHD) { type = g / e.heads; head = g - type * e.heads; }
+        else if (e.layout == QKV_HEAD_QKV) { head = g / 3; type = g - head * 3; }
+        else if (e.layout == QKV_HEAD_KV) { head = g >> 1; type = 1 + (g & 1); }
+        else { type = 0; head = g; }
+        const int dbase = (lane >> 4) << 2;
+        const float* nw = type == 0 ? e.qw : e.kw;
+        const float* nb = type == 0 ? e.qb : e.kb;
+        const bool do_norm = type < 2 && e.norm != QKN_NONE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[j][i];
+                if (p.bias) v[j] += *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * 64 + j * 16 + dbase);
+            }
+            if (do_norm) {
+                float mean = 0.f;
+                if (e.norm == QKN_LAYERNORM) {
+                    float s1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s1 += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    mean = s1 * (1.f / 64.f);
+                }
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = v[j][c] - mean; s2 += d * d; }
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = nw ? *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (e.norm == QKN_LAYERNORM && nb) b = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
+                    v[j] = (v[j] - mean) * r * w + b;
+                }
+            }
+            if (m >= p.M) continue;
+            const int64_t drow = (int64_t)e.dst_row0 + m;
+            if (type < 2) {
+                uint16_t* base = (type == 0 ? e.Q + (((int64_t)batch * e.heads + head) * e.Lq_pad + drow) * 64
+                                            : e.K + (((int64_t)batch * e.heads + head) * e.Lk_pad + drow) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 pk;
+                    pk.x = pack_bf16(v[j][0], v[j][1]);
+                    pk.y = pack_bf16(v[j][2], v[j][3]);
+                    *reinterpret_cast<uint2*>(base + j * 16 + dbase) = pk;
+                }
+            } else {
+                // V^T[d][token]: 16 consecutive tokens (lane&15) per d -> 32-byte segments
+                uint16_t* base = e.Vt + (((int64_t)batch * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
+            }
+        }
+        return;
+    }
     // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}
     const int mrow = m0 + wr * 64 + (lane & 15);
     const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
@@ -184,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
             } else {
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                pk.x = pack_bf16(v[0], v[1]);
+                pk.y = pack_bf16(v[2], v[3]);
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
             }
         }
@@ -223,6 +307,9 @@ hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) {
         case EPI_BF16_GELU_ERF: return launch_epi<EPI_BF16_GELU_ERF>(p, batch, g_gemm_glds, s);
         case EPI_RESID_F32: return launch_epi<EPI_RESID_F32>(p, batch, g_gemm_glds, s);
         case EPI_F32: return launch_epi<EPI_F32>(p, batch, g_gemm_glds, s);
+        case EPI_QKV:
+            if (p.N % 64) return hipErrorInvalidValue;
+            return launch_epi<EPI_QKV>(p, batch, g_gemm_glds, s);
         default: return hipErrorInvalidValue;
     }
 }

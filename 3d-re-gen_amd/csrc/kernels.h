@@ -13,6 +13,26 @@ enum GemmEpilogue {
     EPI_BF16_GELU_ERF = 2,   // C(bf16) = gelu_erf(acc + bias)
     EPI_RESID_F32 = 3,       // C(f32) += gate[b][n] * (acc + bias)      (gate null -> 1)
     EPI_F32 = 4,             // C(f32) = acc + bias
+    EPI_QKV = 5,             // split into attention operands: per-head q/k norm, Q/K [B][H][L][64], V^T [B][H][64][L]
+};
+
+enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
+
+enum QkvLayout {
+    QKV_KHD = 0,       // columns (K H D): q heads | k heads | v heads          (DiT, Dinov2 fused qkv)
+    QKV_HEAD_QKV = 1,  // per head (q,k,v) interleaved, 192 columns per head    (ShapeVAE c_qkv)
+    QKV_HEAD_KV = 2,   // per head (k,v) interleaved, 128 columns per head      (geo decoder c_kv)
+    QKV_Q_ONLY = 3,    // q heads only                                          (geo decoder c_q)
+};
+
+// destination of the EPI_QKV epilogue (what qkv_split_kernel produces, fused into the projection)
+struct QkvEpi {
+    uint16_t* Q; uint16_t* K; uint16_t* Vt;
+    int Lq_pad, Lk_pad;   // allocated rows of Q and of K / V^T
+    int dst_row0;         // first destination row (token offset in the joint sequence)
+    int heads, layout, norm;  // QkvLayout, QkNorm
+    const float *qw, *qb, *kw, *kb;
+    float eps;
 };
 
 struct GemmArgs {
@@ -27,6 +47,7 @@ struct GemmArgs {
     int64_t strideGate;
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
+    QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
@@ -62,7 +83,6 @@ struct LnArgs {
 };
 hipError_t layernorm_launch(const LnArgs& p, hipStream_t s);
 
-enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
 // Split a fused projection output into attention operands, normalising q and k per head (dim 64).
 struct QkvSplitArgs {
     const uint16_t* src; int64_t ld; int64_t src_batch_stride;  // bf16 [B][L][ld]
@@ -81,6 +101,11 @@ hipError_t qkv_split_launch(const QkvSplitArgs& p, hipStream_t s);
 // y[b][n] = act(x[b][:] . W[n][:] + bias[n]); x f32 [B][K], W bf16 [N][K], y f32; B <= 8
 hipError_t gemv_launch(const float* x, int B, int K, const uint16_t* W, int64_t ldw, const float* bias, float* y,
                        int N, int act_silu_in, int act_silu_out, hipStream_t s);
+
+// Many small GEMVs sharing one input x (all adaLN modulations of a DiT forward in one launch)
+struct GemvJob { const uint16_t* W; const float* bias; int64_t ldw; int N; int64_t out_off; };  // y + out_off : [B][N]
+hipError_t gemv_multi_launch(const float* x, int B, int K, const GemvJob* d_jobs, int njobs, float* y, int silu_in,
+                             hipStream_t s);
 
 // t == null: every batch entry uses t_scalar
 hipError_t timestep_embedding_launch(const float* t, float t_scalar, int B, float time_factor, float* out /*[B][256]*/,

@@ -45,6 +45,9 @@ struct Lin {
 
 static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
+static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
+
 struct Model {
     r3g_model_config c{};
     std::unordered_map<std::string, Tensor> w;
@@ -68,6 +71,11 @@ struct Model {
     float* z = nullptr;         // VAE-decoded latents f32 [Nlat][W]
     uint16_t *geoK = nullptr, *geoVt = nullptr;
     bool have_z = false;
+    // all adaLN modulation GEMVs of one DiT forward, batched into one launch
+    GemvJob* mod_jobs = nullptr;
+    int n_mod_jobs = 0;
+    float* mod_all = nullptr;           // [job][B][N]
+    std::vector<int64_t> mod_off;       // per job offset into mod_all
     std::string err;
 
     const Tensor* find(const std::string& name) const {
@@ -137,6 +145,30 @@ static int gemm(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, i
     return R3G_OK;
 }
 
+// projection whose output goes straight to the attention operand layout (EPI_QKV), or the unfused pair
+static int gemm_qkv(Model& m, const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, int n_off, int N, int M,
+                    int K, int batch, const QkvSplitArgs& q, int layout, hipStream_t s) {
+    if (g_fuse_qkv) {
+        GemmArgs p{};
+        p.A = A; p.lda = lda; p.strideA = strideA;
+        p.W = l.w + (int64_t)n_off * l.ldw; p.ldw = l.ldw;
+        p.bias = l.b ? l.b + n_off : nullptr;
+        p.M = M; p.N = N; p.K = K; p.epi = EPI_QKV;
+        p.qkv.Q = q.Q; p.qkv.K = q.K; p.qkv.Vt = q.Vt; p.qkv.Lq_pad = q.Lq_pad; p.qkv.Lk_pad = q.Lk_pad;
+        p.qkv.dst_row0 = q.dst_row0; p.qkv.heads = q.H; p.qkv.layout = layout; p.qkv.norm = q.norm;
+        p.qkv.qw = q.qw; p.qkv.qb = q.qb; p.qkv.kw = q.kw; p.qkv.kb = q.kb; p.qkv.eps = q.eps;
+        hipError_t e = gemm_launch(p, batch, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv)");
+        return R3G_OK;
+    }
+    int rc = gemm(A, lda, strideA, l, n_off, N, const_cast<uint16_t*>(q.src), q.ld, q.src_batch_stride, M, K, EPI_BF16,
+                  nullptr, 0, batch, s);
+    if (rc) return rc;
+    hipError_t e = qkv_split_launch(q, s);
+    if (e != hipSuccess) return hip_fail(e, "qkv_split_launch");
+    return R3G_OK;
+}
+
 static int layernorm(const float* x, int64_t ldx, int64_t xbs, uint16_t* y, int64_t ldy, int64_t ybs, int rows_per_batch,
                      int batch, int C, const float* w, const float* b, const float* scale, const float* shift,
                      int64_t mod_stride, float eps, hipStream_t s) {
@@ -172,6 +204,36 @@ static int dit_modulation(Model& m, const std::string& base, int B, int mult, fl
     return R3G_OK;
 }
 
+// One-time table of every modulation layer (double img/txt, single, final) for gemv_multi_launch.
+static int build_mod_jobs(Model& m) {
+    if (m.mod_jobs) return R3G_OK;
+    const r3g_model_config& c = m.c;
+    std::vector<GemvJob> jobs;
+    m.mod_off.clear();
+    int64_t off = 0;
+    auto add = [&](const std::string& base, int mult) -> int {
+        Lin l;
+        int rc = get_lin(m, base, true, &l);
+        if (rc) return rc;
+        if (l.N != mult * m.H) return fail(R3G_ERR_INVALID, "'%s' has N=%d, expected %d", base.c_str(), l.N, mult * m.H);
+        jobs.push_back(GemvJob{l.w, l.b, l.ldw, l.N, off});
+        m.mod_off.push_back(off);
+        off += 2LL * l.N;  // [B<=2][N]
+        return R3G_OK;
+    };
+    for (int i = 0; i < c.dit_depth_double; ++i) {
+        R3G_RC(add(fmt("model.double_blocks.%d.img_mod.lin", i), 6));
+        R3G_RC(add(fmt("model.double_blocks.%d.txt_mod.lin", i), 6));
+    }
+    for (int i = 0; i < c.dit_depth_single; ++i) R3G_RC(add(fmt("model.single_blocks.%d.modulation.lin", i), 3));
+    R3G_RC(add("model.final_layer.adaLN_modulation.1", 2));
+    R3G_TRY(hipMalloc((void**)&m.mod_jobs, jobs.size() * sizeof(GemvJob)));
+    R3G_TRY(hipMemcpy(m.mod_jobs, jobs.data(), jobs.size() * sizeof(GemvJob), hipMemcpyHostToDevice));
+    R3G_TRY(hipMalloc((void**)&m.mod_all, (size_t)off * sizeof(float)));
+    m.n_mod_jobs = (int)jobs.size();
+    return R3G_OK;
+}
+
 static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_scalar, const uint16_t* cond, float* out,
                        int B, int n_double, int n_single, hipStream_t s) {
     const r3g_model_config& c = m.c;
@@ -193,6 +255,10 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
     R3G_RC(get_lin(m, "model.time_in.out_layer", true, &l));
     R3G_TRY(gemv_launch(m.th, B, H, l.w, l.ldw, l.b, m.vec, H, 0, 0, s));
 
+    if (g_batch_mods) {
+        R3G_RC(build_mod_jobs(m));
+        R3G_TRY(gemv_multi_launch(m.vec, B, H, m.mod_jobs, m.n_mod_jobs, m.mod_all, 1, s));
+    }
     const int nd = n_double < 0 ? c.dit_depth_double : n_double;
     const int ns = n_single < 0 ? c.dit_depth_single : n_single;
     const int64_t catld = 5 * (int64_t)H, cats = (int64_t)Tpad * catld;
@@ -208,12 +274,11 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
             const std::string blk = fmt("model.double_blocks.%d.%s", i, nm);
             // mods: [stream][B][6H] = shift1 scale1 gate1 shift2 scale2 gate2
             float* mm = m.mods + (int64_t)st * 2 * 6 * H;
-            R3G_RC(dit_modulation(m, blk + "_mod.lin", B, 6, mm, s));
+            if (g_batch_mods) mm = m.mod_all + m.mod_off[2 * i + st];
+            else R3G_RC(dit_modulation(m, blk + "_mod.lin", B, 6, mm, s));
             R3G_RC(layernorm(m.f32a + (int64_t)row0 * H, H, xs, m.xn + (int64_t)row0 * H, H, xs, rows, B, H, nullptr, nullptr,
                              mm + H, mm, 6 * H, 1e-6f, s));
             R3G_RC(get_lin(m, blk + "_attn.qkv", c.dit_qkv_bias != 0, &l));
-            R3G_RC(gemm(m.xn + (int64_t)row0 * H, H, xs, l, 0, 3 * H, m.qkv + (int64_t)row0 * qkvld, qkvld, qkvs, rows, H,
-                        EPI_BF16, nullptr, 0, B, s));
             QkvSplitArgs q{};
             q.src = m.qkv + (int64_t)row0 * qkvld; q.ld = qkvld; q.src_batch_stride = qkvs;
             q.q_off = 0; q.k_off = H; q.v_off = 2 * H; q.head_stride = 64;
@@ -221,14 +286,14 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
             q.B = B; q.H = heads; q.L = rows; q.norm = QKN_RMS; q.eps = 1e-6f;
             R3G_RC(get_vec(m, blk + "_attn.norm.query_norm.scale", 64, &q.qw));
             R3G_RC(get_vec(m, blk + "_attn.norm.key_norm.scale", 64, &q.kw));
-            R3G_TRY(qkv_split_launch(q, s));
+            R3G_RC(gemm_qkv(m, m.xn + (int64_t)row0 * H, H, xs, l, 0, 3 * H, rows, H, B, q, QKV_KHD, s));
         }
         R3G_RC(attention(m, B, heads, T, Tpad, T, Tpad, m.cat, catld, cats, m.K, m.Vt, false, s));
         for (int st = 0; st < 2; ++st) {
             const char* nm = st == 0 ? "img" : "txt";
             const int row0 = st == 0 ? 0 : Nl, rows = st == 0 ? Nl : Lc;
             const std::string blk = fmt("model.double_blocks.%d.%s", i, nm);
-            float* mm = m.mods + (st == 0 ? 0 : (int64_t)2 * 6 * H);
+            float* mm = g_batch_mods ? m.mod_all + m.mod_off[2 * i + st] : m.mods + (st == 0 ? 0 : (int64_t)2 * 6 * H);
             float* xr = m.f32a + (int64_t)row0 * H;
             R3G_RC(get_lin(m, blk + "_attn.proj", true, &l));
             R3G_RC(gemm(m.cat + (int64_t)row0 * catld, catld, cats, l, 0, H, xr, H, xs, rows, H, EPI_RESID_F32, mm + 2 * H,
@@ -246,11 +311,11 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
     for (int i = 0; i < ns; ++i) {
         const std::string blk = fmt("model.single_blocks.%d", i);
         float* mm = m.mods;  // [B][3H]: shift scale gate
-        R3G_RC(dit_modulation(m, blk + ".modulation.lin", B, 3, mm, s));
+        if (g_batch_mods) mm = m.mod_all + m.mod_off[2 * c.dit_depth_double + i];
+        else R3G_RC(dit_modulation(m, blk + ".modulation.lin", B, 3, mm, s));
         R3G_RC(layernorm(m.f32a, H, xs, m.xn, H, xs, T, B, H, nullptr, nullptr, mm + H, mm, 3 * H, 1e-6f, s));
         R3G_RC(get_lin(m, blk + ".linear1", true, &l));
         if (l.N != 3 * H + mh) return fail(R3G_ERR_INVALID, "linear1 N mismatch");
-        R3G_RC(gemm(m.xn, H, xs, l, 0, 3 * H, m.qkv, qkvld, qkvs, T, H, EPI_BF16, nullptr, 0, B, s));
         R3G_RC(gemm(m.xn, H, xs, l, 3 * H, mh, m.cat + H, catld, cats, T, H, EPI_BF16_GELU_TANH, nullptr, 0, B, s));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = qkvld; q.src_batch_stride = qkvs;
@@ -259,15 +324,20 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
         q.B = B; q.H = heads; q.L = T; q.norm = QKN_RMS; q.eps = 1e-6f;
         R3G_RC(get_vec(m, blk + ".norm.query_norm.scale", 64, &q.qw));
         R3G_RC(get_vec(m, blk + ".norm.key_norm.scale", 64, &q.kw));
-        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(gemm_qkv(m, m.xn, H, xs, l, 0, 3 * H, T, H, B, q, QKV_KHD, s));
         R3G_RC(attention(m, B, heads, T, Tpad, T, Tpad, m.cat, catld, cats, m.K, m.Vt, false, s));
         R3G_RC(get_lin(m, blk + ".linear2", true, &l));
         R3G_RC(gemm(m.cat, catld, cats, l, 0, H, m.f32a, H, xs, T, H + mh, EPI_RESID_F32, mm + 2 * H, 3 * H, B, s));
     }
     // final layer on the latent rows
-    R3G_RC(get_lin(m, "model.final_layer.adaLN_modulation.1", true, &l));
-    R3G_TRY(gemv_launch(m.vec, B, H, l.w, l.ldw, l.b, m.mods, 2 * H, 1, 0, s));
-    R3G_RC(layernorm(m.f32a, H, xs, m.xn, H, xs, Nl, B, H, nullptr, nullptr, m.mods + H, m.mods, 2 * H, 1e-6f, s));
+    float* fm = m.mods;
+    if (g_batch_mods) {
+        fm = m.mod_all + m.mod_off[2 * c.dit_depth_double + c.dit_depth_single];
+    } else {
+        R3G_RC(get_lin(m, "model.final_layer.adaLN_modulation.1", true, &l));
+        R3G_TRY(gemv_launch(m.vec, B, H, l.w, l.ldw, l.b, fm, 2 * H, 1, 0, s));
+    }
+    R3G_RC(layernorm(m.f32a, H, xs, m.xn, H, xs, Nl, B, H, nullptr, nullptr, fm + H, fm, 2 * H, 1e-6f, s));
     R3G_RC(get_lin(m, "model.final_layer.linear", true, &l));
     R3G_RC(gemm(m.xn, H, xs, l, 0, c.dit_in_channels, out, c.dit_in_channels, (int64_t)Nl * c.dit_in_channels, Nl, H, EPI_F32,
                 nullptr, 0, B, s));
@@ -290,7 +360,6 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
         R3G_RC(get_vec(m, blk + ".ln_1.bias", W, &lb));
         R3G_RC(layernorm(m.z, W, 0, m.xn, W, 0, Nl, 1, W, lw, lb, nullptr, nullptr, 0, 1e-6f, s));
         R3G_RC(get_lin(m, blk + ".attn.c_qkv", c.vae_qkv_bias != 0, &l));
-        R3G_RC(gemm(m.xn, W, 0, l, 0, 3 * W, m.qkv, 3 * W, 0, Nl, W, EPI_BF16, nullptr, 0, 1, s));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = 3 * W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = 64; q.v_off = 128; q.head_stride = 192;  // per-head interleaved (q,k,v)
@@ -303,7 +372,7 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
             R3G_RC(get_vec(m, blk + ".attn.attention.k_norm.weight", 64, &q.kw));
             R3G_RC(get_vec(m, blk + ".attn.attention.k_norm.bias", 64, &q.kb));
         }
-        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(gemm_qkv(m, m.xn, W, 0, l, 0, 3 * W, Nl, W, 1, q, QKV_HEAD_QKV, s));
         R3G_RC(attention(m, 1, heads, Nl, q.Lq_pad, Nl, q.Lk_pad, m.cat, W, 0, m.K, m.Vt, false, s));
         R3G_RC(get_lin(m, blk + ".attn.c_proj", true, &l));
         R3G_RC(gemm(m.cat, W, 0, l, 0, W, m.z, W, 0, Nl, W, EPI_RESID_F32, nullptr, 0, 1, s));
@@ -321,7 +390,6 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
     R3G_RC(get_vec(m, g + ".ln_2.bias", W, &lb));
     R3G_RC(layernorm(m.z, W, 0, m.xn, W, 0, Nl, 1, W, lw, lb, nullptr, nullptr, 0, 1e-6f, s));
     R3G_RC(get_lin(m, g + ".attn.c_kv", c.vae_qkv_bias != 0, &l));
-    R3G_RC(gemm(m.xn, W, 0, l, 0, 2 * W, m.qkv, 2 * W, 0, Nl, W, EPI_BF16, nullptr, 0, 1, s));
     QkvSplitArgs q{};
     q.src = m.qkv; q.ld = 2 * W; q.src_batch_stride = 0;
     q.q_off = -1; q.k_off = 0; q.v_off = 64; q.head_stride = 128;  // per-head interleaved (k,v)
@@ -333,7 +401,7 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
         R3G_RC(get_vec(m, g + ".attn.attention.k_norm.weight", 64, &q.kw));
         R3G_RC(get_vec(m, g + ".attn.attention.k_norm.bias", 64, &q.kb));
     }
-    R3G_TRY(qkv_split_launch(q, s));
+    R3G_RC(gemm_qkv(m, m.xn, W, 0, l, 0, 2 * W, Nl, W, 1, q, QKV_HEAD_KV, s));
     m.have_z = true;
     return R3G_OK;
 }
@@ -372,7 +440,6 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         R3G_TRY(fourier_grid_launch(m.inb, start + off, npad, R, bound, c.vae_num_freqs, c.vae_include_pi, s));
         R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, EPI_F32, nullptr, 0, 1, s));
         R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s));
-        R3G_RC(gemm(m.xn, W, 0, lcq, 0, W, m.qkv, W, 0, n, W, EPI_BF16, nullptr, 0, 1, s));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
@@ -383,7 +450,7 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
         }
-        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
         R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
         R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, EPI_RESID_F32, nullptr, 0, 1, s));
         R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s));
@@ -415,13 +482,12 @@ static int cond_encode(Model& m, const float* img, uint16_t* out, hipStream_t s)
         R3G_RC(get_vec(m, blk + ".norm1.bias", Hc, &b));
         R3G_RC(layernorm(m.f32a, Hc, 0, m.xn, Hc, 0, L, 1, Hc, w, b, nullptr, nullptr, 0, c.cond_ln_eps, s));
         R3G_RC(get_lin(m, blk + ".attention.attention.qkv", true, &l));
-        R3G_RC(gemm(m.xn, Hc, 0, l, 0, 3 * Hc, m.qkv, 3 * Hc, 0, L, Hc, EPI_BF16, nullptr, 0, 1, s));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = 3 * Hc; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = Hc; q.v_off = 2 * Hc; q.head_stride = 64;
         q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Lp; q.Lk_pad = Lp; q.dst_row0 = 0;
         q.B = 1; q.H = heads; q.L = L; q.norm = QKN_NONE; q.eps = 0.f;
-        R3G_TRY(qkv_split_launch(q, s));
+        R3G_RC(gemm_qkv(m, m.xn, Hc, 0, l, 0, 3 * Hc, L, Hc, 1, q, QKV_KHD, s));
         R3G_RC(attention(m, 1, heads, L, Lp, L, Lp, m.cat, Hc, 0, m.K, m.Vt, false, s));
         R3G_RC(get_lin(m, blk + ".attention.output.dense", true, &l));
         R3G_RC(get_vec(m, blk + ".layer_scale1.lambda1", Hc, &ls));
@@ -448,6 +514,8 @@ static int cond_encode(Model& m, const float* img, uint16_t* out, hipStream_t s)
 static void model_free(Model* m) {
     if (!m) return;
     if (m->arena) (void)hipFree(m->arena);
+    if (m->mod_jobs) (void)hipFree(m->mod_jobs);
+    if (m->mod_all) (void)hipFree(m->mod_all);
     delete m;
 }
 
@@ -634,6 +702,15 @@ int r3g_prof_read(int64_t* counts, double* ms, double* work, int n) {
     long long c[PC_COUNT];
     prof_read(c, ms, work);
     for (int i = 0; i < PC_COUNT; ++i) counts[i] = c[i];
+    return R3G_OK;
+}
+
+int r3g_set_option(const char* name, int value) {
+    if (!name) return fail(R3G_ERR_INVALID, "r3g_set_option: null name");
+    if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
+    else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
+    else if (!strcmp(name, "lds_dma")) { gemm_set_glds(value != 0); attn_set_glds(value != 0); }
+    else return fail(R3G_ERR_INVALID, "r3g_set_option: unknown option '%s'", name);
     return R3G_OK;
 }
 

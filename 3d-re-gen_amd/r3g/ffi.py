@@ -47,6 +47,7 @@ SYMBOLS = {
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
     "r3g_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "r3g_set_staging": (_I, [_I]),
+    "r3g_set_option": (_I, [ctypes.c_char_p, _I]),
     "r3g_prof_enable": (_I, [_I]),
     "r3g_prof_read": (_I, [_P, _P, _P, _I]),
 }

@@ -146,6 +146,10 @@ int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d
  * work = algorithmic FLOPs (0,1,4) / bytes (6) summed over the launches since r3g_prof_enable(1). */
 int r3g_prof_enable(int on);
 int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
+/* A/B switches for tests and ablations (defaults 1): "fuse_qkv" (QKV split/norm/transpose in the projection
+ * epilogue vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch),
+ * "lds_dma" (= r3g_set_staging). */
+int r3g_set_option(const char* name, int value);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);
 
