@@ -102,20 +102,35 @@ class ShapeModel:
         self.L = _l.lib()
         self._c = make_config(cfg, grid_chunk)
         with torch.cuda.device(self.device):
-            _l.check(self.L.r3g_model_create(self.ctx, ctypes.byref(self._c)))
-            self._w, scalars = prepare_weights(state_dict, self.device)
-            for name, (t, code) in self._w.items():
-                _l.check(self.L.r3g_model_set_tensor(self.ctx, name.encode(), t.data_ptr(), code, t.shape[0], t.shape[1]))
-            for name, v in scalars.items():
-                _l.check(self.L.r3g_model_set_scalar(self.ctx, name.encode(), v))
-            torch.cuda.synchronize()
+            self._w, self._scalars = prepare_weights(state_dict, self.device)
+            self._install()
         p = cfg["cond"]["image_size"] // cfg["cond"]["patch_size"]
         self.cond_tokens = p * p + 1
         self.num_latents = cfg["vae"]["num_latents"]
         self.in_channels = cfg["dit"]["in_channels"]
 
-    @staticmethod
-    def _s():
+    # The C context holds ONE model (arena + weight table) per device.  Several ShapeModel objects may coexist in a
+    # process (e.g. mini + full, or test fixtures): the one being called re-installs itself if it is not current.
+    _current = {}
+
+    def _install(self):
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            _l.check(self.L.r3g_model_create(self.ctx, ctypes.byref(self._c)))
+            for name, (t, code) in self._w.items():
+                _l.check(self.L.r3g_model_set_tensor(self.ctx, name.encode(), t.data_ptr(), code, t.shape[0], t.shape[1]))
+            for name, v in self._scalars.items():
+                _l.check(self.L.r3g_model_set_scalar(self.ctx, name.encode(), v))
+            torch.cuda.synchronize()
+        ShapeModel._current[self.device.index] = self
+        self._have_z = False
+
+    def _activate(self):
+        if ShapeModel._current.get(self.device.index) is not self:
+            self._install()
+
+    def _s(self):
+        self._activate()
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def cond_encode(self, image):
@@ -152,6 +167,7 @@ class ShapeModel:
             if return_z else None
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_vae_decode(self.ctx, latents.data_ptr(), z.data_ptr() if return_z else None, self._s()))
+        self._have_z = True
         return z
 
     def grid_query(self, bound, octree_resolution, out=None, start=0, count=None):
