@@ -135,8 +135,6 @@ def test_grid_is_independent_of_internal_chunking(tiny):
     other.vae_decode(lat)
     b = other.grid_query(1.01, 12)
     assert torch.equal(a, b)
-    # restore the module-scoped model as the context's current one
-    tiny.gpu = M.ShapeModel(tiny.cfg, tiny.sd, 0, grid_chunk=4096)
 
 
 def test_end_to_end_pipeline_tiny():
