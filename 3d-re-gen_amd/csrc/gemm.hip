@@ -59,14 +59,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *reinterpret_cast<const uint32_t*>(&h);
 }
 
-template <bool GLDS>
+// one operand tile: 128 rows x 64 k = 1024 chunks of 16 B = 16 pieces of 1 KiB, spread over NW waves
+template <bool GLDS, int NW>
 __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int64_t ld, int row0, int rows_valid,
                                            int k0, char* lds_tile, int wid, int lane, int tid) {
-    // one operand tile: 128 rows x 64 k = 1024 chunks of 16 B
     if constexpr (GLDS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wid * 4 + i;  // 1 KiB piece = 8 tile rows
+        for (int i = 0; i < 16 / NW; ++i) {
+            const int piece = wid * (16 / NW) + i;  // 1 KiB piece = 8 tile rows
             const int row = piece * 8 + (lane >> 3);
             const int kc = (lane & 7) ^ ((row >> 1) & 7);
             int gr = row0 + row;
@@ -76,27 +76,33 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
                                              (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
         }
     } else {
-        uint4 v[4];
+        uint4 v[16 / NW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * 256 + tid;
+        for (int i = 0; i < 16 / NW; ++i) {
+            const int c = i * (NW * 64) + tid;
             const int row = c >> 3, kc = c & 7;
             int gr = row0 + row;
             gr = gr < rows_valid ? gr : rows_valid - 1;
             v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)gr * ld + k0 + kc * 8);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * 256 + tid;
+        for (int i = 0; i < 16 / NW; ++i) {
+            const int c = i * (NW * 64) + tid;
             const int row = c >> 3, kc = c & 7;
             *reinterpret_cast<uint4*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v[i];
         }
     }
 }
 
-template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+// NW = 4: waves 2(m) x 2(n), 64x64 per wave.  NW = 8: waves 4(m) x 2(n), 32x64 per wave (a wave always owns 64
+// whole columns = one attention head for the EPI_QKV epilogue).  NS = LDS stages (2: wait for everything each k-tile;
+// 3: LDS-DMA of tile t+2 stays in flight across the barrier -- counted vmcnt + raw s_barrier).
+template <int EPI, bool GLDS, int NW, int NS>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = NW == 4 ? 4 : 2;       // 16-row sub-tiles per wave
+    constexpr int WROWS = MI * 16;
+    constexpr int LOADS = 2 * 16 / NW;        // LDS-DMA instructions per wave per k-tile (A + W)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
@@ -112,52 +118,78 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const uint16_t* W = p.W;
     const int wr = wid >> 1, wc = wid & 1;
 
-    f32x4 acc[4][4];  // [j: n sub-tile][i: m sub-tile]
+    f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    stage_tile<GLDS>(A, p.lda, m0, p.M, 0, smem, wid, lane, tid);
-    stage_tile<GLDS>(W, p.ldw, n0, p.N, 0, smem + TILE_BYTES, wid, lane, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    auto stage = [&](int t, int slot) {
+        char* base = smem + slot * STAGE_BYTES;
+        stage_tile<GLDS, NW>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
+        stage_tile<GLDS, NW>(W, p.ldw, n0, p.N, t * BK, base + TILE_BYTES, wid, lane, tid);
+    };
+    stage(0, 0);
+    if (NS == 3 && nk > 1) stage(1, 1);
+    if (NS == 3 && nk > 1 && GLDS) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     // fragment read offsets (bytes) inside a tile, for the two 32-wide k-steps of a BK=64 tile
-    int offA[4], offB[4];
+    int offA[MI], offB[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rowA = wr * WROWS + i * 16 + (lane & 15);
+        offA[i] = rowA * 128 + ((((lane >> 4)) ^ ((rowA >> 1) & 7)) << 4);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rowA = wr * 64 + i * 16 + (lane & 15);
         const int rowB = wc * 64 + i * 16 + (lane & 15);
-        offA[i] = rowA * 128 + ((((lane >> 4)) ^ ((rowA >> 1) & 7)) << 4);
         offB[i] = rowB * 128 + ((((lane >> 4)) ^ ((rowB >> 1) & 7)) << 4);
     }
 
+    int cur_slot = 0;
     for (int t = 0; t < nk; ++t) {
-        char* cur = smem + (t & 1) * STAGE_BYTES;
-        char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-        if (t + 1 < nk) {
-            stage_tile<GLDS>(A, p.lda, m0, p.M, (t + 1) * BK, nxt, wid, lane, tid);
-            stage_tile<GLDS>(W, p.ldw, n0, p.N, (t + 1) * BK, nxt + TILE_BYTES, wid, lane, tid);
+        const char* cur = smem + cur_slot * STAGE_BYTES;
+        if (NS == 2) {
+            if (t + 1 < nk) stage(t + 1, cur_slot ^ 1);
+        } else {
+            if (t + 2 < nk) stage(t + 2, cur_slot >= 1 ? cur_slot - 1 : 2);  // (cur_slot + 2) % 3
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[MI], b[4];
             // chunk index = kk*4 + (lane>>4); XOR with the row swizzle commutes with adding kk*4 (bit 2)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(cur + (offA[i] ^ (kk << 6)));
-                b[i] = *reinterpret_cast<const bf16x8*>(cur + TILE_BYTES + (offB[i] ^ (kk << 6)));
-            }
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + (offA[i] ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(cur + TILE_BYTES + (offB[i] ^ (kk << 6)));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_slot ^= 1;
+        } else {
+            // tile t+1 must have landed; tile t+2 (issued above, LOADS instructions per wave) may stay in flight
+            if (GLDS && t + 2 < nk) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur_slot = cur_slot == 2 ? 0 : cur_slot + 1;
+        }
     }
 
     if constexpr (EPI == EPI_QKV) {
@@ -176,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         const float* nb = type == 0 ? e.qb : e.kb;
         const bool do_norm = type < 2 && e.norm != QKN_NONE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wr * WROWS + i * 16 + (lane & 15);
             f32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -234,72 +266,115 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
         return;
     }
-    // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}
-    const int mrow = m0 + wr * 64 + (lane & 15);
+    // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}.
+    // All loads (bias, gate, old residual values) are issued before the first store so that the stores are not
+    // serialised behind per-iteration waits.
+    const int mrow = m0 + wr * WROWS + (lane & 15);
     const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
     const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
+    f32x4 biasv[4], gatev[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = ncol + j * 16;
-        if (n >= p.N) continue;  // N is a multiple of 4
-        f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-        f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (EPI == EPI_RESID_F32 && gate) g = *reinterpret_cast<const f32x4*>(gate + n);
+        const int nc = n < p.N ? n : p.N - 4;  // clamped: loads are unconditional, only stores are predicated
+        biasv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gatev[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (EPI == EPI_RESID_F32 && gate) gatev[j] = *reinterpret_cast<const f32x4*>(gate + nc);
+    }
+    const int64_t cbase = (int64_t)batch * p.strideC;
+    if constexpr (EPI == EPI_RESID_F32) {
+        float* X = reinterpret_cast<float*>(p.C) + cbase;
+        f32x4 old[4][MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mrow + i * 16;
-            if (m >= p.M) continue;
-            f32x4 v = acc[j][i] + bias;
-            if (EPI == EPI_BF16_GELU_TANH) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            } else if (EPI == EPI_BF16_GELU_ERF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
+                old[j][i] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
             }
-            const int64_t off = (int64_t)batch * p.strideC + (int64_t)m * p.ldc + n;
-            if (EPI == EPI_RESID_F32) {
-                float* x = reinterpret_cast<float*>(p.C) + off;
-                f32x4 o = *reinterpret_cast<f32x4*>(x);
-                o += g * v;
-                *reinterpret_cast<f32x4*>(x) = o;
-            } else if (EPI == EPI_F32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
-            } else {
-                uint2 pk;
-                pk.x = pack_bf16(v[0], v[1]);
-                pk.y = pack_bf16(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                const f32x4 o = old[j][i] + gatev[j] * (acc[j][i] + biasv[j]);
+                if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = o;
             }
-        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                f32x4 v = acc[j][i] + biasv[j];
+                if (EPI == EPI_BF16_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                } else if (EPI == EPI_BF16_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (n < p.N && m < p.M) {
+                    const int64_t off = cbase + (int64_t)m * p.ldc + n;
+                    if (EPI == EPI_F32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                    } else {
+                        uint2 pk;
+                        pk.x = pack_bf16(v[0], v[1]);
+                        pk.y = pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                    }
+                }
+            }
     }
 }
 
-template <int EPI>
-hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
+template <int EPI, int NW, int NS>
+hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
-    const size_t lds = 2 * STAGE_BYTES;
+    const size_t lds = (size_t)NS * STAGE_BYTES;
+    auto kt = gemm_kernel<EPI, true, NW, NS>;
+    auto kf = gemm_kernel<EPI, false, NW, NS>;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            done = true;
+            (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+    }
     if (glds) {
-        hipLaunchKernelGGL((gemm_kernel<EPI, true>), dim3(tiles), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kt, dim3(tiles), dim3(NW * 64), lds, s, p);
     } else {
-        hipLaunchKernelGGL((gemm_kernel<EPI, false>), dim3(tiles), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kf, dim3(tiles), dim3(NW * 64), lds, s, p);
     }
     return hipGetLastError();
+}
+
+static int g_gemm_waves = 4, g_gemm_stages = 2;
+
+template <int EPI>
+hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
+    if (g_gemm_waves == 8) {
+        return g_gemm_stages == 3 ? launch_cfg<EPI, 8, 3>(p, batch, glds, s) : launch_cfg<EPI, 8, 2>(p, batch, glds, s);
+    }
+    return g_gemm_stages == 3 ? launch_cfg<EPI, 4, 3>(p, batch, glds, s) : launch_cfg<EPI, 4, 2>(p, batch, glds, s);
 }
 
 }  // namespace
 
 static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
+void gemm_set_config(int waves, int stages) {
+    if (waves == 4 || waves == 8) g_gemm_waves = waves;
+    if (stages == 2 || stages == 3) g_gemm_stages = stages;
+}
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
     if (p.K % BK != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        attr_done = true;  // 64 KiB dynamic LDS is within the default limit on gfx950; nothing to raise
-    }
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, batch, g_gemm_glds, s);
