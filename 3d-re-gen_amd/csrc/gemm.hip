@@ -109,10 +109,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
+    // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int batch = wg / (tiles_n * tiles_m);
-    const int rem = wg - batch * (tiles_n * tiles_m);
-    const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
+    constexpr int GN = 8;
+    const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const uint16_t* A = p.A + (int64_t)batch * p.strideA;
     const uint16_t* W = p.W;
@@ -131,14 +140,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
         stage_tile<GLDS, NW>(W, p.ldw, n0, p.N, t * BK, base + TILE_BYTES, wid, lane, tid);
     };
     stage(0, 0);
-    if (NS == 3 && nk > 1) stage(1, 1);
-    if (NS == 3 && nk > 1 && GLDS) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        __builtin_amdgcn_s_barrier();
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // fragment read offsets (bytes) inside a tile, for the two 32-wide k-steps of a BK=64 tile
     int offA[MI], offB[4];
@@ -152,44 +155,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
         const int rowB = wc * 64 + i * 16 + (lane & 15);
         offB[i] = rowB * 128 + ((((lane >> 4)) ^ ((rowB >> 1) & 7)) << 4);
     }
+    // chunk index = kk*4 + (lane>>4); XOR with the row swizzle commutes with adding kk*4 (bit 2 of the chunk)
+    auto load_frags = [&](const char* tile, int kk, bf16x8 (&a)[MI], bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tile + (offA[i] ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(tile + TILE_BYTES + (offB[i] ^ (kk << 6)));
+    };
+    auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+    };
 
-    int cur_slot = 0;
+    // Software pipeline: the fragments of k-step 1 are read while the MFMAs of k-step 0 run; the MFMAs of k-step 1
+    // (registers only) run after the end-of-tile barrier, behind the LDS reads of the NEXT tile's k-step 0.
+    bf16x8 a0[MI], b0[4], a1[MI], b1[4];
+    load_frags(smem, 0, a0, b0);
     for (int t = 0; t < nk; ++t) {
-        const char* cur = smem + cur_slot * STAGE_BYTES;
-        if (NS == 2) {
-            if (t + 1 < nk) stage(t + 1, cur_slot ^ 1);
-        } else {
-            if (t + 2 < nk) stage(t + 2, cur_slot >= 1 ? cur_slot - 1 : 2);  // (cur_slot + 2) % 3
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[MI], b[4];
-            // chunk index = kk*4 + (lane>>4); XOR with the row swizzle commutes with adding kk*4 (bit 2)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + (offA[i] ^ (kk << 6)));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(cur + TILE_BYTES + (offB[i] ^ (kk << 6)));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
-        }
-        if (NS == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur_slot ^= 1;
-        } else {
-            // tile t+1 must have landed; tile t+2 (issued above, LOADS instructions per wave) may stay in flight
-            if (GLDS && t + 2 < nk) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur_slot = cur_slot == 2 ? 0 : cur_slot + 1;
-        }
+        const int slot = t & 1;
+        const char* cur = smem + slot * STAGE_BYTES;
+        if (t + 1 < nk) stage(t + 1, slot ^ 1);
+        load_frags(cur, 1, a1, b1);
+        mma(a0, b0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nk) load_frags(smem + (slot ^ 1) * STAGE_BYTES, 0, a0, b0);
+        mma(a1, b1);
     }
 
     if constexpr (EPI == EPI_QKV) {
@@ -372,7 +366,9 @@ void gemm_set_config(int waves, int stages) {
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 
-hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) {
+hipError_t gemm_launch(const GemmArgs& p_in, int batch, hipStream_t s) {
+    GemmArgs p = p_in;
+    p.batch = batch;
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
     if (p.K % BK != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);

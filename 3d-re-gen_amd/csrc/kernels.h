@@ -47,6 +47,7 @@ struct GemmArgs {
     int64_t strideGate;
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
+    int batch;          // filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
 };
 
