@@ -29,9 +29,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + W
+constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -59,14 +57,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *reinterpret_cast<const uint32_t*>(&h);
 }
 
-// one operand tile: 128 rows x 64 k = 1024 chunks of 16 B = 16 pieces of 1 KiB, spread over NW waves
-template <bool GLDS, int NW>
+// one operand tile: ROWS rows x 64 k, in pieces of 1 KiB (8 rows), spread over NW waves
+template <bool GLDS, int NW, int ROWS>
 __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int64_t ld, int row0, int rows_valid,
                                            int k0, char* lds_tile, int wid, int lane, int tid) {
     if constexpr (GLDS) {
 #pragma unroll
-        for (int i = 0; i < 16 / NW; ++i) {
-            const int piece = wid * (16 / NW) + i;  // 1 KiB piece = 8 tile rows
+        for (int i = 0; i < ROWS / 8 / NW; ++i) {
+            const int piece = wid * (ROWS / 8 / NW) + i;  // 1 KiB piece = 8 tile rows
             const int row = piece * 8 + (lane >> 3);
             const int kc = (lane & 7) ^ ((row >> 1) & 7);
             int gr = row0 + row;
@@ -76,9 +74,9 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
                                              (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
         }
     } else {
-        uint4 v[16 / NW];
+        uint4 v[ROWS / 8 / NW];
 #pragma unroll
-        for (int i = 0; i < 16 / NW; ++i) {
+        for (int i = 0; i < ROWS / 8 / NW; ++i) {
             const int c = i * (NW * 64) + tid;
             const int row = c >> 3, kc = c & 7;
             int gr = row0 + row;
@@ -86,7 +84,7 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
             v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)gr * ld + k0 + kc * 8);
         }
 #pragma unroll
-        for (int i = 0; i < 16 / NW; ++i) {
+        for (int i = 0; i < ROWS / 8 / NW; ++i) {
             const int c = i * (NW * 64) + tid;
             const int row = c >> 3, kc = c & 7;
             *reinterpret_cast<uint4*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v[i];
@@ -100,9 +98,12 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 template <int EPI, bool GLDS, int NW, int NS>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MI = NW == 4 ? 4 : 2;       // 16-row sub-tiles per wave
+    constexpr int WN = NW == 16 ? 4 : 2;      // waves along n (64 columns each)
+    constexpr int WM = NW / WN;               // waves along m
+    constexpr int BM = NW == 16 ? 256 : 128, BN = WN * 64;
+    constexpr int MI = BM / WM / 16;          // 16-row sub-tiles per wave
     constexpr int WROWS = MI * 16;
-    constexpr int LOADS = 2 * 16 / NW;        // LDS-DMA instructions per wave per k-tile (A + W)
+    constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    constexpr int GN = 8;
+    const int GN = p.raster_group > 0 ? p.raster_group : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
     const int group = wg / per_group;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const uint16_t* A = p.A + (int64_t)batch * p.strideA;
     const uint16_t* W = p.W;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WN, wc = wid % WN;
 
     f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
 #pragma unroll
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     const int nk = p.K / BK;
     auto stage = [&](int t, int slot) {
         char* base = smem + slot * STAGE_BYTES;
-        stage_tile<GLDS, NW>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
-        stage_tile<GLDS, NW>(W, p.ldw, n0, p.N, t * BK, base + TILE_BYTES, wid, lane, tid);
+        stage_tile<GLDS, NW, BM>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
+        stage_tile<GLDS, NW, BN>(W, p.ldw, n0, p.N, t * BK, base + TILE_A, wid, lane, tid);
     };
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tile + (offA[i] ^ (kk << 6)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(tile + TILE_BYTES + (offB[i] ^ (kk << 6)));
+        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(tile + TILE_A + (offB[i] ^ (kk << 6)));
     };
     auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[4]) {
 #pragma unroll
@@ -170,20 +171,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
     };
 
-    // Software pipeline: the fragments of k-step 1 are read while the MFMAs of k-step 0 run; the MFMAs of k-step 1
-    // (registers only) run after the end-of-tile barrier, behind the LDS reads of the NEXT tile's k-step 0.
-    bf16x8 a0[MI], b0[4], a1[MI], b1[4];
-    load_frags(smem, 0, a0, b0);
     for (int t = 0; t < nk; ++t) {
         const int slot = t & 1;
         const char* cur = smem + slot * STAGE_BYTES;
         if (t + 1 < nk) stage(t + 1, slot ^ 1);
-        load_frags(cur, 1, a1, b1);
-        mma(a0, b0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI], b[4];
+            load_frags(cur, kk, a, b);
+            mma(a, b);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nk) load_frags(smem + (slot ^ 1) * STAGE_BYTES, 0, a0, b0);
-        mma(a1, b1);
     }
 
     if constexpr (EPI == EPI_QKV) {
@@ -279,23 +278,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     const int64_t cbase = (int64_t)batch * p.strideC;
     if constexpr (EPI == EPI_RESID_F32) {
         float* X = reinterpret_cast<float*>(p.C) + cbase;
-        f32x4 old[4][MI];
+        // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
+        constexpr int JG = NW == 16 ? 1 : 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j0 = 0; j0 < 4; j0 += JG) {
+            f32x4 old[JG][MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int n = ncol + j * 16, m = mrow + i * 16;
-                const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
-                old[j][i] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
-            }
+            for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < MI; ++i) {
+                    const int n = ncol + (j0 + jj) * 16, m = mrow + i * 16;
+                    const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
+                    old[jj][i] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
+                }
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int n = ncol + j * 16, m = mrow + i * 16;
-                const f32x4 o = old[j][i] + gatev[j] * (acc[j][i] + biasv[j]);
-                if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = o;
-            }
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int j = j0 + jj;
+                    const int n = ncol + j * 16, m = mrow + i * 16;
+                    const f32x4 o = old[jj][i] + gatev[j] * (acc[j][i] + biasv[j]);
+                    if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = o;
+                }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -327,8 +332,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
 
 template <int EPI, int NW, int NS>
 hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
+    constexpr int BM = NW == 16 ? 256 : 128, BN = NW == 16 ? 256 : 128;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
-    const size_t lds = (size_t)NS * STAGE_BYTES;
+    const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
     auto kt = gemm_kernel<EPI, true, NW, NS>;
     auto kf = gemm_kernel<EPI, false, NW, NS>;
     if (lds > 64 * 1024) {
@@ -348,29 +354,37 @@ hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
 }
 
 static int g_gemm_waves = 4, g_gemm_stages = 2;
+int g_gemm_raster = 0;
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
-    if (g_gemm_waves == 8) {
-        return g_gemm_stages == 3 ? launch_cfg<EPI, 8, 3>(p, batch, glds, s) : launch_cfg<EPI, 8, 2>(p, batch, glds, s);
+    int waves = g_gemm_waves;
+    if (waves == 0) {  // automatic: 256x256 tiles (16 waves) when they fill the chip well, else 128x128
+        const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
+        const long rounds = (t256 + 255) / 256;
+        waves = (p.N % 256 == 0 && t256 * 10 >= rounds * 256 * 8) ? 16 : (p.N <= 1024 ? 8 : 4);
     }
-    return g_gemm_stages == 3 ? launch_cfg<EPI, 4, 3>(p, batch, glds, s) : launch_cfg<EPI, 4, 2>(p, batch, glds, s);
+    if (waves == 16) return launch_cfg<EPI, 16, 2>(p, batch, glds, s);
+    if (waves == 8) return launch_cfg<EPI, 8, 2>(p, batch, glds, s);
+    return launch_cfg<EPI, 4, 2>(p, batch, glds, s);
 }
 
 }  // namespace
 
 static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
+void gemm_set_raster(int group) { g_gemm_raster = group; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 4 || waves == 8) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 16) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 
 hipError_t gemm_launch(const GemmArgs& p_in, int batch, hipStream_t s) {
     GemmArgs p = p_in;
     p.batch = batch;
+    p.raster_group = g_gemm_raster;
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
-    if (p.K % BK != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
+    if (p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, batch, g_gemm_glds, s);

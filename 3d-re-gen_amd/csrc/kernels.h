@@ -48,13 +48,15 @@ struct GemmArgs {
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
     int batch;          // filled in by gemm_launch
+    int raster_group;   // tile columns per rasterisation group (0 = row-major), filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
-void gemm_set_config(int waves, int stages);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
+void gemm_set_config(int waves, int stages);
+void gemm_set_raster(int group);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
 struct AttnArgs {

@@ -36,15 +36,15 @@ def main():
         w = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
-        for waves, stages in ((4, 2), (8, 2), (4, 3), (8, 3)):
+        for waves, raster in ((4, 0), (4, 8), (8, 0), (16, 0), (16, 4)):
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
-            ffi.check(L.r3g_set_option(b"gemm_stages", stages))
+            ffi.check(L.r3g_set_option(b"gemm_raster", raster))
             ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
                                                         None, M, N, K, epi, 1, s)))
-            out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, stages=stages, ms=ms,
+            out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, ms=ms,
                             tflops=2.0 * M * N * K / ms / 1e9))
         ffi.check(L.r3g_set_option(b"gemm_waves", 4))
-        ffi.check(L.r3g_set_option(b"gemm_stages", 2))
+        ffi.check(L.r3g_set_option(b"gemm_raster", 0))
         ref = timeit(lambda: torch.matmul(a, w.t()))
         out.append(dict(op="torch.matmul(hipBLASLt)", M=M, N=N, K=K, ms=ref, tflops=2.0 * M * N * K / ref / 1e9))
     for (B, H, Lq, Lk, shared) in [(2, 16, 4442, 4442, 0), (1, 16, 3072, 3072, 0), (1, 16, 131072, 3072, 1),
