@@ -113,7 +113,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int GN = p.raster_group > 0 ? p.raster_group : tiles_n;  // 0: plain row-major tile order
+    const int rg = p.raster_group < 0 ? (NW == 16 ? 4 : 0) : p.raster_group;   // <0: automatic
+    const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
     const int group = wg / per_group;
@@ -353,16 +354,18 @@ hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     return hipGetLastError();
 }
 
-static int g_gemm_waves = 4, g_gemm_stages = 2;
-int g_gemm_raster = 0;
+static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
+int g_gemm_raster = -1;
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     int waves = g_gemm_waves;
-    if (waves == 0) {  // automatic: 256x256 tiles (16 waves) when they fill the chip well, else 128x128
+    if (waves == 0) {
+        // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
+        // flop) win for long K or very many tiles; 128x128 with 8 waves wins slightly for N <= 1024, 4 waves otherwise
         const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        const long rounds = (t256 + 255) / 256;
-        waves = (p.N % 256 == 0 && t256 * 10 >= rounds * 256 * 8) ? 16 : (p.N <= 1024 ? 8 : 4);
+        if (p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 16;
+        else waves = p.N <= 1024 ? 8 : 4;
     }
     if (waves == 16) return launch_cfg<EPI, 16, 2>(p, batch, glds, s);
     if (waves == 8) return launch_cfg<EPI, 8, 2>(p, batch, glds, s);
@@ -382,7 +385,7 @@ void gemm_set_config(int waves, int stages) {
 hipError_t gemm_launch(const GemmArgs& p_in, int batch, hipStream_t s) {
     GemmArgs p = p_in;
     p.batch = batch;
-    p.raster_group = g_gemm_raster;
+    p.raster_group = g_gemm_raster;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
     if (p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);

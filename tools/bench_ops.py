@@ -43,8 +43,8 @@ def main():
                                                         None, M, N, K, epi, 1, s)))
             out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, ms=ms,
                             tflops=2.0 * M * N * K / ms / 1e9))
-        ffi.check(L.r3g_set_option(b"gemm_waves", 4))
-        ffi.check(L.r3g_set_option(b"gemm_raster", 0))
+        ffi.check(L.r3g_set_option(b"gemm_waves", 0))
+        ffi.check(L.r3g_set_option(b"gemm_raster", -1))
         ref = timeit(lambda: torch.matmul(a, w.t()))
         out.append(dict(op="torch.matmul(hipBLASLt)", M=M, N=N, K=K, ms=ref, tflops=2.0 * M * N * K / ref / 1e9))
     for (B, H, Lq, Lk, shared) in [(2, 16, 4442, 4442, 0), (1, 16, 3072, 3072, 0), (1, 16, 131072, 3072, 1),
