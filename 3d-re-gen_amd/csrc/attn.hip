@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     const int b = blockIdx.z, hd = blockIdx.y;
     const int ql = lane & 31, hh = lane >> 5;
     const int q = blockIdx.x * 128 + wid * 32 + ql;
+    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    if ((int)blockIdx.x * 128 >= Lq) return;  // ragged: shorter batch entries have fewer query tiles
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
     const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
         offV[kb] = row * 128 + ((((row >> 1) & 7)) << 4) + 8 * hh;  // chunk 0 swizzled; chunk c via XOR (c<<4)
     }
 
-    const int ntiles = (p.Lk + KV_TILE - 1) / KV_TILE;
+    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
+    const int bias_key = p.ragged ? p.bias_key[b] : -1;
+    const float bias_raw = p.ragged ? p.bias_log2[b] / sc : 0.f;  // added to the raw (unscaled) score
     stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, 0, smem, wid, lane, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -146,7 +150,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (key_base + kb * 32 + (r & 3) + 8 * (r >> 2) >= p.Lk) s[kb][r] = -INFINITY;
+                {
+                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= Lk) s[kb][r] = -INFINITY;
+                    else if (key == bias_key) s[kb][r] += bias_raw;
+                }
         }
         float mloc = s[0][0];
 #pragma unroll
@@ -197,15 +205,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    const bool pad_tail = ntiles * KV_TILE > p.Lk;
+    const bool pad_tail = ntiles * KV_TILE > Lk;
     for (int t = 0; t < ntiles - 1; ++t) tile(std::false_type{}, t);
     if (pad_tail) tile(std::true_type{}, ntiles - 1);
     else tile(std::false_type{}, ntiles - 1);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < p.Lq) {
-        uint16_t* dst = p.O + (int64_t)b * p.strideO + (int64_t)q * p.ldo + hd * 64;
+    if (q < Lq) {
+        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
+        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -224,9 +234,23 @@ static bool g_attn_glds = true;
 void attn_set_glds(bool on) { g_attn_glds = on; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
+    if (p.ragged) {
+        if (p.B > 2) return hipErrorInvalidValue;
+        for (int b = 0; b < p.B; ++b) {
+            if (p.lq_b[b] <= 0 || p.lk_b[b] <= 0 || p.lq_b[b] > p.Lq_pad || p.lk_b[b] > p.Lk_pad) return hipErrorInvalidValue;
+            const int nt = (p.lk_b[b] + 63) / 64;
+            if (p.bias_key[b] >= 0 && (p.bias_key[b] < (nt - 1) * 64 || nt * 64 == p.lk_b[b] || p.bias_key[b] >= p.lk_b[b]))
+                return hipErrorInvalidValue;  // the weighted key must sit in the last, padded tile
+        }
+    }
     if (p.Lq_pad % 128 || p.Lk_pad % 64 || p.Lk <= 0 || p.Lq <= 0 || p.Lk > p.Lk_pad || p.Lq > p.Lq_pad)
         return hipErrorInvalidValue;
-    ProfScope ps(PC_ATTN, 4.0 * (double)p.B * p.H * p.Lq * p.Lk * 64, s);
+    double pairs = (double)p.B * p.Lq * p.Lk;
+    if (p.ragged) {
+        pairs = 0;
+        for (int b = 0; b < p.B; ++b) pairs += (double)p.lq_b[b] * p.lk_b[b];
+    }
+    ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
     dim3 grid(p.Lq_pad / 128, p.H, p.B);
     if (g_attn_glds) {
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, p);

@@ -237,10 +237,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
                 }
             }
             if (m >= p.M) continue;
-            const int64_t drow = (int64_t)e.dst_row0 + m;
+            int64_t drow = (int64_t)e.dst_row0 + m;
+            int ob = batch;
+            if (e.nseg > 0) {
+                bool hit = false;
+#pragma unroll
+                for (int sgi = 0; sgi < 3; ++sgi)
+                    if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
+                        hit = true;
+                        ob = e.seg_batch[sgi];
+                        drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
+                    }
+                if (!hit) continue;
+            }
             if (type < 2) {
-                uint16_t* base = (type == 0 ? e.Q + (((int64_t)batch * e.heads + head) * e.Lq_pad + drow) * 64
-                                            : e.K + (((int64_t)batch * e.heads + head) * e.Lk_pad + drow) * 64);
+                uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
+                                            : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint2 pk;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
                 }
             } else {
                 // V^T[d][token]: 16 consecutive tokens (lane&15) per d -> 32-byte segments
-                uint16_t* base = e.Vt + (((int64_t)batch * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
+                uint16_t* base = e.Vt + (((int64_t)ob * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll

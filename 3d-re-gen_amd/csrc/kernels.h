@@ -33,6 +33,10 @@ struct QkvEpi {
     int heads, layout, norm;  // QkvLayout, QkNorm
     const float *qw, *qb, *kw, *kb;
     float eps;
+    // optional row segments (nseg > 0): GEMM row m in [seg_m0, seg_m1) goes to attention batch seg_batch, destination
+    // row seg_dst + (m - seg_m0); rows in no segment are dropped.  nseg == 0: batch = GEMM batch, row = dst_row0 + m.
+    int nseg;
+    int seg_m0[3], seg_m1[3], seg_batch[3], seg_dst[3];
 };
 
 struct GemmArgs {
@@ -70,6 +74,16 @@ struct AttnArgs {
     int Lk, Lk_pad;      // valid / allocated keys (Lk_pad % 64 == 0)
     int kv_batch_stride_zero;  // 1: K/V are shared by all batches (cross attention with B query chunks)
     float scale;         // softmax scale (1/sqrt(64))
+    // Ragged mode (B <= 2; CFG with a de-duplicated unconditional context): per-batch lengths, an output row map
+    //   row(b, q) = q < o_split[b] ? o_row0[b] + q : o_row_split[b] + (q - o_split[b])     (strideO ignored)
+    // and one key per batch that stands for `2^bias_log2[b]` identical keys (its score gets +bias_log2 in log2 units;
+    // the key must lie in the last, padded key tile).  bias_key < 0: none.
+    int ragged;
+    int lq_b[2], lk_b[2];
+    int64_t o_row0[2], o_row_split[2];
+    int o_split[2];
+    int bias_key[2];
+    float bias_log2[2];
 };
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s);

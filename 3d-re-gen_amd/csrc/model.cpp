@@ -47,6 +47,7 @@ static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
+static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
 
 struct Model {
     r3g_model_config c{};
@@ -344,6 +345,140 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
     return R3G_OK;
 }
 
+// ---- DiT under classifier-free guidance with a de-duplicated unconditional context -------------------------
+// The unconditional context is `zeros_like(cond)` (upstream conditioner.unconditional_embedding): after cond_in its
+// Lc tokens are identical, and every layer keeps them identical (same input, same per-token ops, same attention
+// row).  They are therefore carried as ONE token whose key counts Lc times in the softmax (score + log2(Lc) in the
+// log2 domain) -- exactly the same function, 3073 instead of 4442 tokens for that batch entry.
+// Global row layout of all row-indexed buffers (both CFG entries share timestep, hence modulation and gates):
+//   [0, Nl) latent(cond) | [Nl, Nl+Lc) cond tokens | row T = Nl+Lc: the unconditional context token | pad |
+//   [R1, R1+Nl) latent(uncond),  R1 = roundup(T+1, 128).   txt-stream GEMMs see Lc+1 contiguous rows.
+static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, const uint16_t* cond, const uint16_t* uncond_row,
+                                 float* out2, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    const int H = m.H, Nl = c.vae_num_latents, Lc = m.Lc, T = m.T, Tpad = m.Tpad, heads = m.Hd;
+    const int R1 = (int)rup(T + 1, 128), Rtot = R1 + Nl, Ltxt = Lc + 1;
+    if (Rtot > 2 * Tpad) return fail(R3G_ERR_INVALID, "dedup layout does not fit the activation arena");
+    const int64_t latS = (int64_t)R1 * H;  // row stride between the two latent blocks
+    const int64_t catld = 5 * (int64_t)H, qkvld = 3 * (int64_t)H;
+    const int mh = c.dit_mlp_hidden;
+    Lin l;
+    // inputs: the same latents for both entries; cond rows + the single unconditional row
+    R3G_TRY(cast_pad_launch(x_lat, c.dit_in_channels, m.inb, m.cin_pad, Nl, c.dit_in_channels, m.cin_pad, 1.0f, s));
+    R3G_RC(get_lin(m, "model.latent_in", true, &l));
+    R3G_RC(gemm(m.inb, m.cin_pad, 0, l, 0, H, m.f32a, H, latS, Nl, m.cin_pad, EPI_F32, nullptr, 0, 2, s));
+    uint16_t* ctx_rows = m.qkv;  // scratch: [Lc+1][context_dim] bf16
+    R3G_TRY(hipMemcpyAsync(ctx_rows, cond, (size_t)Lc * c.dit_context_dim * 2, hipMemcpyDeviceToDevice, s));
+    R3G_TRY(hipMemcpyAsync(ctx_rows + (int64_t)Lc * c.dit_context_dim, uncond_row, (size_t)c.dit_context_dim * 2,
+                           hipMemcpyDeviceToDevice, s));
+    R3G_RC(get_lin(m, "model.cond_in", true, &l));
+    R3G_RC(gemm(ctx_rows, c.dit_context_dim, 0, l, 0, H, m.f32a + (int64_t)Nl * H, H, 0, Ltxt, c.dit_context_dim, EPI_F32,
+                nullptr, 0, 1, s));
+    R3G_TRY(timestep_embedding_launch(nullptr, t_scalar, 1, c.dit_time_factor, m.temb, s));
+    R3G_RC(get_lin(m, "model.time_in.in_layer", true, &l));
+    R3G_TRY(gemv_launch(m.temb, 1, 256, l.w, l.ldw, l.b, m.th, H, 0, 1, s));
+    R3G_RC(get_lin(m, "model.time_in.out_layer", true, &l));
+    R3G_TRY(gemv_launch(m.th, 1, H, l.w, l.ldw, l.b, m.vec, H, 0, 0, s));
+    R3G_RC(build_mod_jobs(m));
+    R3G_TRY(gemv_multi_launch(m.vec, 1, H, m.mod_jobs, m.n_mod_jobs, m.mod_all, 1, s));
+
+    AttnArgs at{};
+    at.Q = m.Q; at.K = m.K; at.Vt = m.Vt; at.O = m.cat; at.ldo = catld; at.strideO = 0;
+    at.B = 2; at.H = heads; at.Lq = T; at.Lq_pad = Tpad; at.Lk = T; at.Lk_pad = Tpad; at.scale = 0.125f;
+    at.ragged = 1;
+    at.lq_b[0] = T; at.lk_b[0] = T; at.lq_b[1] = Nl + 1; at.lk_b[1] = Nl + 1;
+    at.o_row0[0] = 0; at.o_split[0] = T; at.o_row_split[0] = 0;
+    at.o_row0[1] = R1; at.o_split[1] = Nl; at.o_row_split[1] = T;
+    at.bias_key[0] = -1; at.bias_log2[0] = 0.f;
+    at.bias_key[1] = Nl; at.bias_log2[1] = log2f((float)Lc);
+
+    auto qkv_args = [&](const std::string& qn, const std::string& kn, QkvSplitArgs* q) -> int {
+        *q = QkvSplitArgs{};
+        q->q_off = 0; q->k_off = H; q->v_off = 2 * H; q->head_stride = 64;
+        q->Q = m.Q; q->K = m.K; q->Vt = m.Vt; q->Lq_pad = Tpad; q->Lk_pad = Tpad;
+        q->H = heads; q->norm = QKN_RMS; q->eps = 1e-6f;
+        R3G_RC(get_vec(m, qn, 64, &q->qw));
+        R3G_RC(get_vec(m, kn, 64, &q->kw));
+        return R3G_OK;
+    };
+    auto launch_qkv = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, int batch, const QkvSplitArgs& q, int nseg,
+                          const int (*seg)[4]) -> int {
+        GemmArgs p{};
+        p.A = A; p.lda = H; p.strideA = strideA; p.W = lin.w; p.ldw = lin.ldw; p.bias = lin.b;
+        p.M = M; p.N = 3 * H; p.K = H; p.epi = EPI_QKV;
+        p.qkv.Q = q.Q; p.qkv.K = q.K; p.qkv.Vt = q.Vt; p.qkv.Lq_pad = q.Lq_pad; p.qkv.Lk_pad = q.Lk_pad;
+        p.qkv.dst_row0 = 0; p.qkv.heads = heads; p.qkv.layout = QKV_KHD; p.qkv.norm = q.norm;
+        p.qkv.qw = q.qw; p.qkv.kw = q.kw; p.qkv.eps = q.eps; p.qkv.nseg = nseg;
+        for (int i = 0; i < nseg; ++i) {
+            p.qkv.seg_m0[i] = seg[i][0]; p.qkv.seg_m1[i] = seg[i][1]; p.qkv.seg_batch[i] = seg[i][2]; p.qkv.seg_dst[i] = seg[i][3];
+        }
+        hipError_t e = gemm_launch(p, batch, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv dedup)");
+        return R3G_OK;
+    };
+
+    for (int i = 0; i < c.dit_depth_double; ++i) {
+        const std::string bi = fmt("model.double_blocks.%d.img", i), bt = fmt("model.double_blocks.%d.txt", i);
+        const float* mi = m.mod_all + m.mod_off[2 * i];
+        const float* mt = m.mod_all + m.mod_off[2 * i + 1];
+        QkvSplitArgs q;
+        // img stream: two latent blocks (batch 2, stride R1 rows)
+        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + H, mi, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, bi + "_attn.qkv", c.dit_qkv_bias != 0, &l));
+        R3G_RC(qkv_args(bi + "_attn.norm.query_norm.scale", bi + "_attn.norm.key_norm.scale", &q));
+        R3G_RC(launch_qkv(m.xn, latS, l, Nl, 2, q, 0, nullptr));
+        // txt stream: Lc cond tokens (entry 0) + 1 unconditional token (entry 1)
+        float* xt = m.f32a + (int64_t)Nl * H;
+        uint16_t* xnt = m.xn + (int64_t)Nl * H;
+        R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + H, mt, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, bt + "_attn.qkv", c.dit_qkv_bias != 0, &l));
+        R3G_RC(qkv_args(bt + "_attn.norm.query_norm.scale", bt + "_attn.norm.key_norm.scale", &q));
+        const int seg_t[2][4] = {{0, Lc, 0, Nl}, {Lc, Lc + 1, 1, Nl}};
+        R3G_RC(launch_qkv(xnt, 0, l, Ltxt, 1, q, 2, seg_t));
+        hipError_t e = attention_launch(at, s);
+        if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
+        // img: proj + mlp
+        R3G_RC(get_lin(m, bi + "_attn.proj", true, &l));
+        R3G_RC(gemm(m.cat, catld, (int64_t)R1 * catld, l, 0, H, m.f32a, H, latS, Nl, H, EPI_RESID_F32, mi + 2 * H, 0, 2, s));
+        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + 4 * H, mi + 3 * H, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, bi + "_mlp.0", true, &l));
+        R3G_RC(gemm(m.xn, H, latS, l, 0, mh, m.cat + H, catld, (int64_t)R1 * catld, Nl, H, EPI_BF16_GELU_TANH, nullptr, 0, 2, s));
+        R3G_RC(get_lin(m, bi + "_mlp.2", true, &l));
+        R3G_RC(gemm(m.cat + H, catld, (int64_t)R1 * catld, l, 0, H, m.f32a, H, latS, Nl, mh, EPI_RESID_F32, mi + 5 * H, 0, 2, s));
+        // txt: proj + mlp
+        uint16_t* catt = m.cat + (int64_t)Nl * catld;
+        R3G_RC(get_lin(m, bt + "_attn.proj", true, &l));
+        R3G_RC(gemm(catt, catld, 0, l, 0, H, xt, H, 0, Ltxt, H, EPI_RESID_F32, mt + 2 * H, 0, 1, s));
+        R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + 4 * H, mt + 3 * H, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, bt + "_mlp.0", true, &l));
+        R3G_RC(gemm(xnt, H, 0, l, 0, mh, catt + H, catld, 0, Ltxt, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, s));
+        R3G_RC(get_lin(m, bt + "_mlp.2", true, &l));
+        R3G_RC(gemm(catt + H, catld, 0, l, 0, H, xt, H, 0, Ltxt, mh, EPI_RESID_F32, mt + 5 * H, 0, 1, s));
+    }
+    const int seg_s[3][4] = {{0, T, 0, 0}, {T, T + 1, 1, Nl}, {R1, R1 + Nl, 1, 0}};
+    for (int i = 0; i < c.dit_depth_single; ++i) {
+        const std::string blk = fmt("model.single_blocks.%d", i);
+        const float* mm = m.mod_all + m.mod_off[2 * c.dit_depth_double + i];
+        R3G_RC(layernorm(m.f32a, H, 0, m.xn, H, 0, Rtot, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s));
+        R3G_RC(get_lin(m, blk + ".linear1", true, &l));
+        R3G_RC(gemm(m.xn, H, 0, l, 3 * H, mh, m.cat + H, catld, 0, Rtot, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, s));
+        QkvSplitArgs q;
+        R3G_RC(qkv_args(blk + ".norm.query_norm.scale", blk + ".norm.key_norm.scale", &q));
+        R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+        hipError_t e = attention_launch(at, s);
+        if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
+        R3G_RC(get_lin(m, blk + ".linear2", true, &l));
+        R3G_RC(gemm(m.cat, catld, 0, l, 0, H, m.f32a, H, 0, Rtot, H + mh, EPI_RESID_F32, mm + 2 * H, 0, 1, s));
+    }
+    const float* fm = m.mod_all + m.mod_off[2 * c.dit_depth_double + c.dit_depth_single];
+    R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, fm + H, fm, 0, 1e-6f, s));
+    R3G_RC(get_lin(m, "model.final_layer.linear", true, &l));
+    R3G_RC(gemm(m.xn, H, latS, l, 0, c.dit_in_channels, out2, c.dit_in_channels, (int64_t)Nl * c.dit_in_channels, Nl, H, EPI_F32,
+                nullptr, 0, 2, s));
+    (void)qkvld;
+    return R3G_OK;
+}
+
 // ---- VAE transformer + geo-decoder K/V -------------------------------------------------------------
 static int vae_decode(Model& m, const float* latents, hipStream_t s) {
     const r3g_model_config& c = m.c;
@@ -627,7 +762,7 @@ int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint
 }
 
 int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
-                    float shift, void* stream) {
+                    float shift, int uncond_uniform, void* stream) {
     NEED_MODEL("r3g_flow_sample");
     if (!d_latents || !d_cond2 || steps < 1) return fail(R3G_ERR_INVALID, "r3g_flow_sample: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -640,10 +775,16 @@ int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int
     }
     sig[steps] = 1.0f;
     float* x2 = m->v2 + 2 * n;  // [2][n] duplicated latents (CFG batch)
+    const bool dedup = g_cfg_dedup && uncond_uniform != 0;
+    const uint16_t* uncond = d_cond2 + (int64_t)m->Lc * m->c.dit_context_dim;
     for (int i = 0; i < steps; ++i) {
-        R3G_TRY(hipMemcpyAsync(x2, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
-        R3G_TRY(hipMemcpyAsync(x2 + n, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
-        R3G_RC(dit_forward(*m, x2, nullptr, sig[i], d_cond2, m->v2, 2, -1, -1, s));
+        if (dedup) {
+            R3G_RC(dit_forward_cfg_dedup(*m, d_latents, sig[i], d_cond2, uncond, m->v2, s));
+        } else {
+            R3G_TRY(hipMemcpyAsync(x2, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
+            R3G_TRY(hipMemcpyAsync(x2 + n, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
+            R3G_RC(dit_forward(*m, x2, nullptr, sig[i], d_cond2, m->v2, 2, -1, -1, s));
+        }
         R3G_TRY(cfg_euler_launch(d_latents, m->v2, n, guidance_scale, sig[i + 1] - sig[i], s));
     }
     return R3G_OK;
@@ -709,6 +850,7 @@ int r3g_set_option(const char* name, int value) {
     if (!name) return fail(R3G_ERR_INVALID, "r3g_set_option: null name");
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
+    else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);
     else if (!strcmp(name, "gemm_stages")) gemm_set_config(0, value);
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);

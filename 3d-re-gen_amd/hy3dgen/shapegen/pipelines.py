@@ -137,7 +137,7 @@ class Hunyuan3DDiTPipeline:
         cond2 = self.encode_cond(cond_inputs["image"])
         latents = self.prepare_latents(generator)
         latents = self.model.flow_sample(latents, cond2, num_inference_steps, guidance_scale,
-                                         self.cfg["sched"].get("shift", 1.0))
+                                         self.cfg["sched"].get("shift", 1.0), uncond_uniform=True)  # zeros_like(cond)
         self.model.vae_decode(latents)
         grid = self.model.grid_query(box_v, octree_resolution)
         self.timings["grid_s"] = time.perf_counter() - t0

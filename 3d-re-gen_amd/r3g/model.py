@@ -152,13 +152,16 @@ class ShapeModel:
                                             x.shape[0], n_double, n_single, self._s()))
         return out
 
-    def flow_sample(self, latents, cond2, steps, guidance_scale, shift=1.0):
-        """latents f32 [N,C] (modified in place and returned), cond2 bf16 [2,Lc,D] = [cond, uncond]"""
+    def flow_sample(self, latents, cond2, steps, guidance_scale, shift=1.0, uncond_uniform=None):
+        """latents f32 [N,C] (modified in place and returned), cond2 bf16 [2,Lc,D] = [cond, uncond].
+        uncond_uniform: all unconditional tokens identical (None = check on the device)."""
         latents = latents.to(self.device, torch.float32).contiguous()
         cond2 = cond2.to(self.device, torch.bfloat16).contiguous()
+        if uncond_uniform is None:
+            uncond_uniform = bool((cond2[1] == cond2[1, :1]).all().item())
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_flow_sample(self.ctx, latents.data_ptr(), cond2.data_ptr(), int(steps),
-                                            float(guidance_scale), float(shift), self._s()))
+                                            float(guidance_scale), float(shift), int(bool(uncond_uniform)), self._s()))
         return latents
 
     def vae_decode(self, latents, return_z=False):

@@ -117,9 +117,12 @@ int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint
 /* The denoising loop of Hunyuan3DDiTFlowMatchingPipeline.__call__ with classifier-free guidance:
  * sigmas = linspace(0,1,steps) (+ FlowMatchEulerDiscreteScheduler shift), per step
  *   v = DiT(cat([x]*2), sigma, d_cond2);  v = v_u + g (v_c - v_u);  x += (sigma_next - sigma) v
- * d_latents f32 [num_latents][in_channels] in/out; d_cond2 bf16 [2][tokens][dim] = [cond, uncond]. */
+ * d_latents f32 [num_latents][in_channels] in/out; d_cond2 bf16 [2][tokens][dim] = [cond, uncond].
+ * uncond_uniform != 0 declares that all tokens of the unconditional context are identical (upstream:
+ * zeros_like(cond)); they are then carried as ONE token that counts `tokens` times in the softmax -- the same
+ * function with 31 % fewer rows in that batch entry (switch "cfg_dedup" of r3g_set_option turns this off). */
 int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
-                    float shift, void* stream);
+                    float shift, int uncond_uniform, void* stream);
 
 /* ShapeVAE.forward(latents / scale_factor) (post_kl + transformer) and the geo decoder's K/V of the
  * result (computed once; upstream recomputes them for every chunk).  d_z_out (optional) f32
@@ -148,7 +151,7 @@ int r3g_prof_enable(int on);
 int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
 /* A/B switches for tests and ablations (defaults 1): "fuse_qkv" (QKV split/norm/transpose in the projection
  * epilogue vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch),
- * "lds_dma" (= r3g_set_staging). */
+ * "lds_dma" (= r3g_set_staging), "cfg_dedup", "gemm_waves" (0 auto | 4 | 8 | 16), "gemm_raster". */
 int r3g_set_option(const char* name, int value);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);

@@ -227,3 +227,36 @@ def test_fused_and_unfused_paths_agree(tiny):
     with torch.no_grad():
         ref = tiny.oracle.model(x, t, cond)
     assert rel_l2(a, ref) <= 1e-2 and rel_l2(b, ref) <= 1e-2
+
+
+def test_cfg_dedup_is_the_same_function(tiny):
+    """The unconditional context (zeros) carried as one weighted token must reproduce the plain CFG batch."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x, _, cond = _inputs(tiny, 12)
+    lat0 = x[0]
+    a = tiny.gpu.flow_sample(lat0.clone(), cond, 5, 5.0).clone()          # cond[1] == 0 -> de-duplicated path
+    try:
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 0))
+        b = tiny.gpu.flow_sample(lat0.clone(), cond, 5, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
+    assert rel_l2(a, b) <= 5e-3
+    ref = tiny.oracle.sample(cond, lat0[None].clone(), 5, 5.0)[0]
+    assert rel_l2(a, ref) <= 3e-2 and rel_l2(b, ref) <= 3e-2
+    # a non-uniform "unconditional" context must take the general path (auto-detected) and still match the oracle
+    cond_nu = cond.clone()
+    cond_nu[1] = torch.randn_like(cond_nu[1]).to(torch.bfloat16).float()
+    c = tiny.gpu.flow_sample(lat0.clone(), cond_nu, 3, 2.0)
+    ref = tiny.oracle.sample(cond_nu, lat0[None].clone(), 3, 2.0)[0]
+    assert rel_l2(c, ref) <= 3e-2
+
+
+def test_cfg_dedup_full_width(wide):
+    import torch
+    x, _, cond = _inputs(wide, 5)
+    lat0 = x[0]
+    out = wide.gpu.flow_sample(lat0.clone(), cond, 2, 5.0)
+    ref = wide.oracle.sample(cond, lat0[None].clone(), 2, 5.0)[0]
+    assert rel_l2(out, ref) <= 3e-2
