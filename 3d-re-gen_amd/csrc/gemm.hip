@@ -95,12 +95,13 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 // NW = 4: waves 2(m) x 2(n), 64x64 per wave.  NW = 8: waves 4(m) x 2(n), 32x64 per wave (a wave always owns 64
 // whole columns = one attention head for the EPI_QKV epilogue).  NS = LDS stages (2: wait for everything each k-tile;
 // 3: LDS-DMA of tile t+2 stays in flight across the barrier -- counted vmcnt + raw s_barrier).
-template <int EPI, bool GLDS, int NW, int NS>
+template <int EPI, bool GLDS, int NW, int BIG>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WN = NW == 16 ? 4 : 2;      // waves along n (64 columns each)
+    // BIG = 1: 256x256 tile (16 waves of 64x64, or 8 waves of 128x64); BIG = 0: 128x128 (4 waves 64x64 / 8 waves 32x64)
+    constexpr int WN = BIG ? 4 : 2;           // waves along n (64 columns each)
     constexpr int WM = NW / WN;               // waves along m
-    constexpr int BM = NW == 16 ? 256 : 128, BN = WN * 64;
+    constexpr int BM = BIG ? 256 : 128, BN = WN * 64;
     constexpr int MI = BM / WM / 16;          // 16-row sub-tiles per wave
     constexpr int WROWS = MI * 16;
     constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int rg = p.raster_group < 0 ? (NW == 16 ? 4 : 0) : p.raster_group;   // <0: automatic
+    const int rg = p.raster_group < 0 ? (BIG ? 4 : 0) : p.raster_group;   // <0: automatic
     const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (EPI == EPI_RESID_F32) {
         float* X = reinterpret_cast<float*>(p.C) + cbase;
         // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
-        constexpr int JG = NW == 16 ? 1 : 4;
+        constexpr int JG = BIG ? 1 : 4;
 #pragma unroll
         for (int j0 = 0; j0 < 4; j0 += JG) {
             f32x4 old[JG][MI];
@@ -343,13 +344,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <int EPI, int NW, int NS>
+template <int EPI, int NW, int BIG>
 hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
-    constexpr int BM = NW == 16 ? 256 : 128, BN = NW == 16 ? 256 : 128;
+    constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
-    const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
-    auto kt = gemm_kernel<EPI, true, NW, NS>;
-    auto kf = gemm_kernel<EPI, false, NW, NS>;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+    auto kt = gemm_kernel<EPI, true, NW, BIG>;
+    auto kf = gemm_kernel<EPI, false, NW, BIG>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -379,9 +380,10 @@ hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
         if (p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 16;
         else waves = p.N <= 1024 ? 8 : 4;
     }
-    if (waves == 16) return launch_cfg<EPI, 16, 2>(p, batch, glds, s);
-    if (waves == 8) return launch_cfg<EPI, 8, 2>(p, batch, glds, s);
-    return launch_cfg<EPI, 4, 2>(p, batch, glds, s);
+    if (waves == 16) return launch_cfg<EPI, 16, 1>(p, batch, glds, s);
+    if (waves == 9) return launch_cfg<EPI, 8, 1>(p, batch, glds, s);   // 256x256 tile, 8 waves of 128x64
+    if (waves == 8) return launch_cfg<EPI, 8, 0>(p, batch, glds, s);
+    return launch_cfg<EPI, 4, 0>(p, batch, glds, s);
 }
 
 }  // namespace
@@ -390,7 +392,7 @@ static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 16) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 16) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 
