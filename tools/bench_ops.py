@@ -36,13 +36,16 @@ def main():
         w = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
-        for waves, raster in ((4, 0), (8, 0), (16, 4), (9, 4), (9, 0)):
+        for waves, raster in ((4, 0), (8, 0), (9, 4), (0, -1)):
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
             ffi.check(L.r3g_set_option(b"gemm_raster", raster))
-            ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
-                                                        None, M, N, K, epi, 1, s)))
-            out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, ms=ms,
-                            tflops=2.0 * M * N * K / ms / 1e9))
+            for pers in (1, 0):
+                ffi.check(L.r3g_set_option(b"gemm_persistent", pers))
+                ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                                                            None, M, N, K, epi, 1, s)))
+                out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, persistent=pers, ms=ms,
+                                tflops=2.0 * M * N * K / ms / 1e9))
+            ffi.check(L.r3g_set_option(b"gemm_persistent", 1))
         ffi.check(L.r3g_set_option(b"gemm_waves", 0))
         ffi.check(L.r3g_set_option(b"gemm_raster", -1))
         ref = timeit(lambda: torch.matmul(a, w.t()))
