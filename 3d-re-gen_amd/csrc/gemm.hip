@@ -107,37 +107,44 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Persistent workgroups: logical tile ids L = blockIdx.x, + gridDim.x, ...  Each id goes through
-    //  (1) the XCD-aware bijective remap (block b runs on XCD b % 8: ids = x mod 8 map to one contiguous chunk) and
-    //  (2) the L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group.
+    // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
+    // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int total = tiles_n * tiles_m * p.batch;
     const int rg = p.raster_group < 0 ? (BIG ? 4 : 0) : p.raster_group;   // <0: automatic
     const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
-    auto decode = [&](int L, int& m0, int& n0, int& batch) {
-        const int q = total >> 3, r = total & 7, xcd = L & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        const int group = wg / per_group;
-        const int within = wg - group * per_group;
-        const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
-        const int rowi = within / gn_cur;
-        const int tn = group * GN + (within - rowi * gn_cur);
-        batch = rowi / tiles_m;
-        m0 = (rowi - batch * tiles_m) * BM;
-        n0 = tn * BN;
-    };
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = p.A + (int64_t)batch * p.strideA;
     const uint16_t* W = p.W;
     const int wr = wid / WN, wc = wid % WN;
-    const int nk = p.K / BK;
 
     f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
-    auto stage = [&](int m0, int n0, int batch, int t, int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int t, int slot) {
         char* base = smem + slot * STAGE_BYTES;
-        stage_tile<GLDS, NW, BM>(p.A + (int64_t)batch * p.strideA, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
+        stage_tile<GLDS, NW, BM>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
         stage_tile<GLDS, NW, BN>(W, p.ldw, n0, p.N, t * BK, base + TILE_A, wid, lane, tid);
     };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // fragment read offsets (bytes) inside a tile, for the two 32-wide k-steps of a BK=64 tile
     int offA[MI], offB[4];
@@ -166,213 +173,182 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
     };
 
-    auto epilogue = [&](const int m0, const int n0, const int batch) {
-        if constexpr (EPI == EPI_QKV) {
-            // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
-            // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
-            const QkvEpi& e = p.qkv;
-            const int g = (n0 + wc * 64) >> 6;
-            if (n0 + wc * 64 >= p.N) return;
-            int type, head;  // 0 q, 1 k, 2 v
-            if (e.layout == QKV_KHD) { type = g / e.heads; head = g - type * e.heads; }
-            else if (e.layout == QKV_HEAD_QKV) { head = g / 3; type = g - head * 3; }
-            else if (e.layout == QKV_HEAD_KV) { head = g >> 1; type = 1 + (g & 1); }
-            else { type = 0; head = g; }
-            const int dbase = (lane >> 4) << 2;
-            const float* nw = type == 0 ? e.qw : e.kw;
-            const float* nb = type == 0 ? e.qb : e.kb;
-            const bool do_norm = type < 2 && e.norm != QKN_NONE;
-    #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wr * WROWS + i * 16 + (lane & 15);
-                f32x4 v[4];
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[j][i];
-                    if (p.bias) v[j] += *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * 64 + j * 16 + dbase);
-                }
-                if (do_norm) {
-                    float mean = 0.f;
-                    if (e.norm == QKN_LAYERNORM) {
-                        float s1 = 0.f;
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j) s1 += v[j][0] + v[j][1] + v[j][2] + v[j][3];
-                        s1 += __shfl_xor(s1, 16, 64);
-                        s1 += __shfl_xor(s1, 32, 64);
-                        mean = s1 * (1.f / 64.f);
-                    }
-                    float s2 = 0.f;
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-    #pragma unroll
-                        for (int c = 0; c < 4; ++c) { const float d = v[j][c] - mean; s2 += d * d; }
-                    s2 += __shfl_xor(s2, 16, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 w = nw ? *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase) : (f32x4){1.f, 1.f, 1.f, 1.f};
-                        f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (e.norm == QKN_LAYERNORM && nb) b = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
-                        v[j] = (v[j] - mean) * r * w + b;
-                    }
-                }
-                if (m >= p.M) continue;
-                int64_t drow = (int64_t)e.dst_row0 + m;
-                int ob = batch;
-                if (e.nseg > 0) {
-                    bool hit = false;
-    #pragma unroll
-                    for (int sgi = 0; sgi < 3; ++sgi)
-                        if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
-                            hit = true;
-                            ob = e.seg_batch[sgi];
-                            drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
-                        }
-                    if (!hit) continue;
-                }
-                if (type < 2) {
-                    uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
-                                                : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint2 pk;
-                        pk.x = pack_bf16(v[j][0], v[j][1]);
-                        pk.y = pack_bf16(v[j][2], v[j][3]);
-                        *reinterpret_cast<uint2*>(base + j * 16 + dbase) = pk;
-                    }
-                } else {
-                    // V^T[d][token]: 16 consecutive tokens (lane&15) per d -> 32-byte segments
-                    uint16_t* base = e.Vt + (((int64_t)ob * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-    #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
-                }
-            }
-            return;
+    for (int t = 0; t < nk; ++t) {
+        const int slot = t & 1;
+        const char* cur = smem + slot * STAGE_BYTES;
+        if (t + 1 < nk) stage(t + 1, slot ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI], b[4];
+            load_frags(cur, kk, a, b);
+            mma(a, b);
         }
-        // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}.
-        // All loads (bias, gate, old residual values) are issued before the first store so that the stores are not
-        // serialised behind per-iteration waits.
-        const int mrow = m0 + wr * WROWS + (lane & 15);
-        const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
-        const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
-        f32x4 biasv[4], gatev[4];
-    #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol + j * 16;
-            const int nc = n < p.N ? n : p.N - 4;  // clamped: loads are unconditional, only stores are predicated
-            biasv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            gatev[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
-            if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
-            if (EPI == EPI_RESID_F32 && gate) gatev[j] = *reinterpret_cast<const f32x4*>(gate + nc);
-        }
-        const int64_t cbase = (int64_t)batch * p.strideC;
-        if constexpr (EPI == EPI_RESID_F32) {
-            float* X = reinterpret_cast<float*>(p.C) + cbase;
-            // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
-            constexpr int JG = BIG ? 1 : 4;
-    #pragma unroll
-            for (int j0 = 0; j0 < 4; j0 += JG) {
-                f32x4 old[JG][MI];
-    #pragma unroll
-                for (int jj = 0; jj < JG; ++jj)
-    #pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int n = ncol + (j0 + jj) * 16, m = mrow + i * 16;
-                        const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
-                        old[jj][i] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
-                    }
-    #pragma unroll
-                for (int jj = 0; jj < JG; ++jj)
-    #pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int j = j0 + jj;
-                        const int n = ncol + j * 16, m = mrow + i * 16;
-                        const f32x4 o = old[jj][i] + gatev[j] * (acc[j][i] + biasv[j]);
-                        if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = o;
-                    }
-            }
-        } else {
-    #pragma unroll
-            for (int j = 0; j < 4; ++j)
-    #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int n = ncol + j * 16, m = mrow + i * 16;
-                    f32x4 v = acc[j][i] + biasv[j];
-                    if (EPI == EPI_BF16_GELU_TANH) {
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                    } else if (EPI == EPI_BF16_GELU_ERF) {
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if (n < p.N && m < p.M) {
-                        const int64_t off = cbase + (int64_t)m * p.ldc + n;
-                        if (EPI == EPI_F32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
-                        } else {
-                            uint2 pk;
-                            pk.x = pack_bf16(v[0], v[1]);
-                            pk.y = pack_bf16(v[2], v[3]);
-                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
-                        }
-                    }
-                }
-        }
-    };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
-    // Main loop.  The first k-tile of the NEXT output tile is staged during the last k-iteration of the current
-    // one, so only the very first tile of a workgroup pays the load latency before its first MFMA.
-    int L = blockIdx.x;
-    if (L >= total) return;
-    int m0, n0, batch;
-    decode(L, m0, n0, batch);
-    stage(m0, n0, batch, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int slot = 0;
-    while (true) {
-        const int Ln = L + (int)gridDim.x;
-        const bool has_next = Ln < total;
-        int m1 = 0, n1 = 0, b1 = 0;
-        if (has_next) decode(Ln, m1, n1, b1);
+    if constexpr (EPI == EPI_QKV) {
+        // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
+        // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
+        const QkvEpi& e = p.qkv;
+        const int g = (n0 + wc * 64) >> 6;
+        if (n0 + wc * 64 >= p.N) return;
+        int type, head;  // 0 q, 1 k, 2 v
+        if (e.layout == QKV_KHD) { type = g / e.heads; head = g - type * e.heads; }
+        else if (e.layout == QKV_HEAD_QKV) { head = g / 3; type = g - head * 3; }
+        else if (e.layout == QKV_HEAD_KV) { head = g >> 1; type = 1 + (g & 1); }
+        else { type = 0; head = g; }
+        const int dbase = (lane >> 4) << 2;
+        const float* nw = type == 0 ? e.qw : e.kw;
+        const float* nb = type == 0 ? e.qb : e.kb;
+        const bool do_norm = type < 2 && e.norm != QKN_NONE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wr * WROWS + i * 16 + (lane & 15);
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[j][i];
+                if (p.bias) v[j] += *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * 64 + j * 16 + dbase);
+            }
+            if (do_norm) {
+                float mean = 0.f;
+                if (e.norm == QKN_LAYERNORM) {
+                    float s1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s1 += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    mean = s1 * (1.f / 64.f);
+                }
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = v[j][c] - mean; s2 += d * d; }
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = nw ? *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (e.norm == QKN_LAYERNORM && nb) b = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
+                    v[j] = (v[j] - mean) * r * w + b;
+                }
+            }
+            if (m >= p.M) continue;
+            int64_t drow = (int64_t)e.dst_row0 + m;
+            int ob = batch;
+            if (e.nseg > 0) {
+                bool hit = false;
+#pragma unroll
+                for (int sgi = 0; sgi < 3; ++sgi)
+                    if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
+                        hit = true;
+                        ob = e.seg_batch[sgi];
+                        drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
+                    }
+                if (!hit) continue;
+            }
+            if (type < 2) {
+                uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
+                                            : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 pk;
+                    pk.x = pack_bf16(v[j][0], v[j][1]);
+                    pk.y = pack_bf16(v[j][2], v[j][3]);
+                    *reinterpret_cast<uint2*>(base + j * 16 + dbase) = pk;
+                }
+            } else {
+                // V^T[d][token]: 16 consecutive tokens (lane&15) per d -> 32-byte segments
+                uint16_t* base = e.Vt + (((int64_t)ob * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
+            }
+        }
+        return;
+    }
+    // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}.
+    // All loads (bias, gate, old residual values) are issued before the first store so that the stores are not
+    // serialised behind per-iteration waits.
+    const int mrow = m0 + wr * WROWS + (lane & 15);
+    const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
+    const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
+    f32x4 biasv[4], gatev[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = ncol + j * 16;
+        const int nc = n < p.N ? n : p.N - 4;  // clamped: loads are unconditional, only stores are predicated
+        biasv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gatev[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (EPI == EPI_RESID_F32 && gate) gatev[j] = *reinterpret_cast<const f32x4*>(gate + nc);
+    }
+    const int64_t cbase = (int64_t)batch * p.strideC;
+    if constexpr (EPI == EPI_RESID_F32) {
+        float* X = reinterpret_cast<float*>(p.C) + cbase;
+        // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
+        constexpr int JG = BIG ? 1 : 4;
+#pragma unroll
+        for (int j0 = 0; j0 < 4; j0 += JG) {
+            f32x4 old[JG][MI];
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int n = ncol + (j0 + jj) * 16, m = mrow + i * 16;
+                    const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
+                    old[jj][i] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
+                }
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int j = j0 + jj;
+                    const int n = ncol + j * 16, m = mrow + i * 16;
+                    const f32x4 o = old[jj][i] + gatev[j] * (acc[j][i] + biasv[j]);
+                    if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = o;
+                }
+        }
+    } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < nk; ++t) {
-            const char* cur = smem + slot * STAGE_BYTES;
-            if (t + 1 < nk) stage(m0, n0, batch, t + 1, slot ^ 1);
-            else if (has_next) stage(m1, n1, b1, 0, slot ^ 1);
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                f32x4 v = acc[j][i] + biasv[j];
+                if (EPI == EPI_BF16_GELU_TANH) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 a[MI], b[4];
-                load_frags(cur, kk, a, b);
-                mma(a, b);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                } else if (EPI == EPI_BF16_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (n < p.N && m < p.M) {
+                    const int64_t off = cbase + (int64_t)m * p.ldc + n;
+                    if (EPI == EPI_F32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                    } else {
+                        uint2 pk;
+                        pk.x = pack_bf16(v[0], v[1]);
+                        pk.y = pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                    }
+                }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            slot ^= 1;
-        }
-        epilogue(m0, n0, batch);
-        if (!has_next) break;
-        L = Ln; m0 = m1; n0 = n1; batch = b1;
     }
 }
-
-static int g_num_cu = 256;
-static bool g_gemm_persistent = true;
 
 template <int EPI, int NW, int BIG>
 hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
     const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-    const int slots = g_num_cu * (BIG ? 1 : 2);  // resident workgroups (LDS-limited)
-    const int grid = g_gemm_persistent && tiles > slots ? slots : tiles;
     auto kt = gemm_kernel<EPI, true, NW, BIG>;
     auto kf = gemm_kernel<EPI, false, NW, BIG>;
     if (lds > 64 * 1024) {
@@ -384,9 +360,9 @@ hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
         }
     }
     if (glds) {
-        hipLaunchKernelGGL(kt, dim3(grid), dim3(NW * 64), lds, s, p);
+        hipLaunchKernelGGL(kt, dim3(tiles), dim3(NW * 64), lds, s, p);
     } else {
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, s, p);
+        hipLaunchKernelGGL(kf, dim3(tiles), dim3(NW * 64), lds, s, p);
     }
     return hipGetLastError();
 }
@@ -415,8 +391,6 @@ hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
 static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
-void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
-void gemm_set_num_cu(int n) { if (n > 0) g_num_cu = n; }
 void gemm_set_config(int waves, int stages) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 16) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;

@@ -60,9 +60,7 @@ hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
 void gemm_set_config(int waves, int stages);
-void gemm_set_raster(int group);
-void gemm_set_persistent(bool on);  // persistent workgroups with next-tile prefetch (default) vs one tile per workgroup
-void gemm_set_num_cu(int n);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
+void gemm_set_raster(int group);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
 struct AttnArgs {

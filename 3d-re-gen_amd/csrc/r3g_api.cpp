@@ -8,7 +8,6 @@
 
 #include "../../include/r3g.h"
 #include "r3g_ctx.h"
-#include "kernels.h"
 
 namespace r3g {
 static thread_local char g_err[512] = "";
@@ -68,7 +67,6 @@ int r3g_create(int device, r3g_ctx** out) {
     if (!c) return fail(R3G_ERR_HIP, "out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    gemm_set_num_cu(c->num_cu);
     e = hipHostMalloc((void**)&c->h_small, 64, hipHostMallocDefault);
     if (e != hipSuccess) {
         delete c;

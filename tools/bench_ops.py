@@ -39,13 +39,10 @@ def main():
         for waves, raster in ((4, 0), (8, 0), (9, 4), (0, -1)):
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
             ffi.check(L.r3g_set_option(b"gemm_raster", raster))
-            for pers in (1, 0):
-                ffi.check(L.r3g_set_option(b"gemm_persistent", pers))
-                ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
-                                                            None, M, N, K, epi, 1, s)))
-                out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, persistent=pers, ms=ms,
-                                tflops=2.0 * M * N * K / ms / 1e9))
-            ffi.check(L.r3g_set_option(b"gemm_persistent", 1))
+            ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                                                        None, M, N, K, epi, 1, s)))
+            out.append(dict(op="gemm", M=M, N=N, K=K, epi=epi, waves=waves, raster=raster, ms=ms,
+                            tflops=2.0 * M * N * K / ms / 1e9))
         ffi.check(L.r3g_set_option(b"gemm_waves", 0))
         ffi.check(L.r3g_set_option(b"gemm_raster", -1))
         ref = timeit(lambda: torch.matmul(a, w.t()))
