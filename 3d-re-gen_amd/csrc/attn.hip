@@ -228,10 +228,236 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant: inside one wave the QK^T MFMAs of key tile t+1 are issued in the same basic block as
+// the exponentials / sums / bf16 packing of tile t, and the row-max reduction of tile t+1 sits beside the PV MFMAs of
+// tile t (an in-order wave only overlaps its matrix and vector pipes when the two instruction kinds are interleaved
+// in program order).  K tiles therefore live in a 3-deep LDS ring (loaded two tiles ahead), V^T tiles in a 2-deep one.
+template <bool GLDS>
+__device__ __forceinline__ void stage_half(const uint16_t* __restrict__ g, int64_t ld, int64_t row_elems0, int col0,
+                                           char* lds, int wid, int lane, int tid) {
+    // one 8 KiB tile = 64 rows of 128 B; source row r starts at g + (row_elems0 + r*ld) + col0
+    if constexpr (GLDS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int row = piece * 8 + (lane >> 3);
+            const int kc = (lane & 7) ^ ((row >> 1) & 7);
+            const uint16_t* src = g + row_elems0 + (int64_t)row * ld + col0 + kc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+        }
+    } else {
+        uint4 v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 256 + tid;
+            const int row = c >> 3, kc = c & 7;
+            v[i] = *reinterpret_cast<const uint4*>(g + row_elems0 + (int64_t)row * ld + col0 + kc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 256 + tid;
+            const int row = c >> 3, kc = c & 7;
+            *reinterpret_cast<uint4*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v[i];
+        }
+    }
+}
+
+template <bool GLDS>
+__global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * TILE_B];  // K ring: 0,1,2 ; V^T ring: 3,4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = blockIdx.x * 128 + wid * 32 + ql;
+    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    if ((int)blockIdx.x * 128 >= Lq) return;
+    const int kvb = p.kv_batch_stride_zero ? 0 : b;
+    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
+    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
+    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)q * 64 + ks * 16 + hh * 8);
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;
+    int offK[2], offV[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + ql;
+        offK[kb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);
+        offV[kb] = row * 128 + ((((row >> 1) & 7)) << 4) + 8 * hh;
+    }
+    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
+    const bool pad_tail = ntiles * KV_TILE > Lk;
+    const int bias_key = p.ragged ? p.bias_key[b] : -1;
+    const float bias_raw = p.ragged ? p.bias_log2[b] / sc : 0.f;
+
+    auto stage_k = [&](int t, int slot) { stage_half<GLDS>(Kg, 64, (int64_t)t * KV_TILE * 64, 0, smem + slot * TILE_B, wid, lane, tid); };
+    auto stage_v = [&](int t, int slot) { stage_half<GLDS>(Vtg, p.Lk_pad, 0, t * KV_TILE, smem + (3 + slot) * TILE_B, wid, lane, tid); };
+    auto qk = [&](const char* kt, f32x16 (&sv)[2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (offK[kb] ^ (ks << 5)));
+                sv[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sv[kb], 0, 0, 0);
+            }
+        }
+    };
+
+    stage_k(0, 0);
+    stage_v(0, 0);
+    if (ntiles > 1) stage_k(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 s_cur[2], s_nxt[2];
+    qk(smem, s_cur);
+    float mloc_nxt = 0.f;  // row max of s_nxt, reduced beside the PV MFMAs
+
+    auto iter = [&](auto masked, auto has_next, const int t, const int kslot_next, const int vslot) {
+        if (t + 2 < ntiles) stage_k(t + 2, kslot_next == 2 ? 0 : kslot_next + 1);
+        if (t + 1 < ntiles) stage_v(t + 1, vslot ^ 1);
+        // ---- row max of tile t and (rarely) the rescale of the running state
+        float mloc;
+        if constexpr (decltype(masked)::value) {
+            const int key_base = t * KV_TILE + 4 * hh;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key_base + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= Lk) s_cur[kb][r] = -INFINITY;
+                    else if (key == bias_key) s_cur[kb][r] += bias_raw;
+                }
+            mloc = s_cur[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s_cur[kb][r]);
+        } else {
+            if (t == 0) {
+                mloc = s_cur[0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s_cur[kb][r]);
+            } else {
+                mloc = mloc_nxt;
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        if (__any(mloc > m_run)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mb = m_run * sc;
+        // ---- region A: QK^T of tile t+1 (matrix pipe)  ||  exp / sum / pack of tile t (vector pipe)
+        if constexpr (decltype(has_next)::value) qk(smem + kslot_next * TILE_B, s_nxt);
+        float psum = 0.f;
+        uint32_t pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][2 * e], sc, -mb));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][2 * e + 1], sc, -mb));
+                psum += p0 + p1;
+                pk[kb][e] = pack_bf16(p0, p1);
+            }
+        l_run += psum;
+        if constexpr (decltype(has_next)::value) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x402, 14, 0);  // 14 VALU / TRANS
+            }
+        }
+        // ---- region B: PV of tile t (matrix pipe)  ||  row max of tile t+1 (vector pipe)
+        const char* vt = smem + (3 + vslot) * TILE_B;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pk[kb][4 * ks2 + e];
+                const int c = 4 * kb + 2 * ks2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    union { bf16x4 h[2]; bf16x8 v; } vf;
+                    vf.h[0] = *reinterpret_cast<const bf16x4*>(vt + (offV[db] ^ (c << 4)));
+                    vf.h[1] = *reinterpret_cast<const bf16x4*>(vt + (offV[db] ^ ((c + 1) << 4)));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+                }
+            }
+        if constexpr (decltype(has_next)::value) {
+            float mx = s_nxt[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_nxt[kb][r]);
+            mloc_nxt = mx;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (decltype(has_next)::value) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) s_cur[kb] = s_nxt[kb];
+        }
+    };
+
+    int ks_next = 1, vs = 0;  // LDS slots of K(t+1) and V(t)
+    for (int t = 0; t < ntiles - 1; ++t) {
+        iter(std::false_type{}, std::true_type{}, t, ks_next, vs);
+        ks_next = ks_next == 2 ? 0 : ks_next + 1;
+        vs ^= 1;
+    }
+    if (pad_tail) iter(std::true_type{}, std::false_type{}, ntiles - 1, ks_next, vs);
+    else iter(std::false_type{}, std::false_type{}, ntiles - 1, ks_next, vs);
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < Lq) {
+        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
+        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        uint16_t* dst = p.O + orow + hd * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk2;
+                pk2.x = pack_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                pk2.y = pack_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(dst + db * 32 + 8 * g + 4 * hh) = pk2;
+            }
+    }
+}
+
 }  // namespace
 
 static bool g_attn_glds = true;
+static bool g_attn_pipelined = true;
 void attn_set_glds(bool on) { g_attn_glds = on; }
+void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.ragged) {
@@ -252,7 +478,10 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     }
     ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
     dim3 grid(p.Lq_pad / 128, p.H, p.B);
-    if (g_attn_glds) {
+    if (g_attn_pipelined) {
+        if (g_attn_glds) hipLaunchKernelGGL(attn_kernel_sp<true>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(attn_kernel_sp<false>, grid, dim3(256), 0, s, p);
+    } else if (g_attn_glds) {
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, s, p);
