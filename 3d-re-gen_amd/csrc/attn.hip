@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
 }  // namespace
 
 static bool g_attn_glds = true;
-static bool g_attn_pipelined = true;
+static bool g_attn_pipelined = false;  // measured slower than the plain kernel (2 vs 3 waves/SIMD): profiles/r01_attention_variants.md
 void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 

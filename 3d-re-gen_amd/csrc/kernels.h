@@ -59,7 +59,7 @@ struct GemmArgs {
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
-void attn_set_pipelined(bool on);  // software-pipelined attention kernel (default) vs the plain one
+void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
 void gemm_set_config(int waves, int stages);
 void gemm_set_raster(int group);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
