@@ -330,6 +330,29 @@ R3G_DEV unsigned load_corners(const float* g, int nx, int ny, int x, int y, int 
     return flags;
 }
 
+// Sign field and range flags of a cell without forming the (value - level) doubles: (double)f - level > 0 is exactly
+// (double)f > level (IEEE subtraction of distinct doubles never rounds to zero), so inactive cells cost 8 compares.
+R3G_DEV unsigned load_signs(const float* g, int nx, int ny, int x, int y, int z, double level, int* index) {
+    const int64_t sy = nx, sz = (int64_t)nx * ny;
+    const float* p = g + (int64_t)z * sz + (int64_t)y * sy + x;
+    float f[8];
+    f[0] = p[0]; f[1] = p[1]; f[2] = p[sy + 1]; f[3] = p[sy];
+    f[4] = p[sz]; f[5] = p[sz + 1]; f[6] = p[sz + sy + 1]; f[7] = p[sz + sy];
+    int idx = 0;
+    unsigned flags = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double d = (double)f[k];
+        if (d > level) idx |= 1 << k;
+        else if (d <= level) flags |= R3G_MC_FLAG_LE;   // not greater and ordered
+        else flags |= R3G_MC_FLAG_NAN;
+        if (d == level) flags |= R3G_MC_FLAG_GE;
+    }
+    if (idx) flags |= R3G_MC_FLAG_GE;
+    *index = idx;
+    return flags;
+}
+
 R3G_DEV unsigned classify_cell(const double* v, int index, bool classic, int x, int y, int z) {
     if (index == 0 || index == 255) return 0;
     const Tiling t = select_tiling(v, index, classic);

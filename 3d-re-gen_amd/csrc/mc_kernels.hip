@@ -56,17 +56,40 @@ __global__ __launch_bounds__(kBlock) void mc_classify(const float* __restrict__ 
                                                       unsigned long long* __restrict__ chunk_sums,
                                                       unsigned* __restrict__ status) {
     __shared__ unsigned long long wave_tot[kBlock / 64];
-    __shared__ unsigned s_flags;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t c = b * kBlock + tid;
-    if (tid == 0) s_flags = 0;
     unsigned rec = 0, flags = 0;
+    int x = 0, y = 0, z = 0, index = 0;
     if (c < ncells) {
-        int x, y, z, index;
-        cell_coords(c, cx, cy, x, y, z);
+        // coordinates: one (wave-uniform) division for the block's first cell, then at most a few wraps per thread
+        int x0, y0, z0;
+        cell_coords(b * kBlock, cx, cy, x0, y0, z0);
+        x = x0 + tid; y = y0; z = z0;
+        if (cx >= kBlock) {
+            if (x >= cx) { x -= cx; if (++y >= cy) { y = 0; ++z; } }
+        } else {
+            cell_coords(c, cx, cy, x, y, z);
+        }
+        flags = load_signs(grid, nx, ny, x, y, z, level, &index);
+    }
+    const bool active = index != 0 && index != 255;
+    // range flags: one global atomic per wave, and only while it would still change the status word
+    {
+        const unsigned long long le = __ballot(flags & R3G_MC_FLAG_LE), ge = __ballot(flags & R3G_MC_FLAG_GE),
+                                 nn = __ballot(flags & R3G_MC_FLAG_NAN);
+        const unsigned wf = (le ? R3G_MC_FLAG_LE : 0u) | (ge ? R3G_MC_FLAG_GE : 0u) | (nn ? R3G_MC_FLAG_NAN : 0u);
+        if (lane == 0 && (wf & ~*(volatile unsigned*)status)) atomicOr(status, wf);
+    }
+    // most blocks contain no surface cell: they publish zeros and leave before the tiling / scan work
+    if (!__syncthreads_or(active ? 1 : 0)) {
+        if (tid == 0) blk[b] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    if (active) {
         double v[8];
-        flags = load_corners(grid, nx, ny, x, y, z, level, v, &index);
+        int idx2;
+        load_corners(grid, nx, ny, x, y, z, level, v, &idx2);
         rec = classify_cell(v, index, classic != 0, x, y, z);
     }
     // packed counters: [0..15] new vertices, [16..31] triangles, [32..47] active cells
@@ -75,12 +98,7 @@ __global__ __launch_bounds__(kBlock) void mc_classify(const float* __restrict__ 
                                     ((unsigned long long)(rec ? 1u : 0u) << 32);
     const unsigned long long incl = wave_inclusive_scan(mine, lane);
     if (lane == 63) wave_tot[wid] = incl;
-    // OR-reduce the range flags over the wave
-    unsigned wf = flags;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wf |= __shfl_xor(wf, d, 64);
     __syncthreads();
-    if (lane == 0 && wf) atomicOr(&s_flags, wf);
     unsigned long long base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) {
@@ -94,14 +112,11 @@ __global__ __launch_bounds__(kBlock) void mc_classify(const float* __restrict__ 
         const unsigned arank = (unsigned)((excl >> 32) & 0xFFFFu);
         act[(size_t)b * kBlock + arank] = make_uint2(rec, (unsigned)tid | (vloc << 8) | (tloc << 20));
     }
-    __syncthreads();
     if (tid == 0) {
         const unsigned sv = (unsigned)(total & 0xFFFFu), st = (unsigned)((total >> 16) & 0xFFFFu);
         const unsigned sa = (unsigned)((total >> 32) & 0xFFFFu);
         blk[b] = make_uint4(sv, st, sa, 0u);
         if (sv | st) atomicAdd(&chunk_sums[b / kChunk], (unsigned long long)sv | ((unsigned long long)st << 32));
-        const unsigned f = s_flags;
-        if (f & ~*(volatile unsigned*)status) atomicOr(status, f);
     }
 }
 

@@ -38,6 +38,10 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
+# HBM-side traffic of the GEMM family per launch, from rocprofv3 PMC passes (profiles/r01_pmc_traffic.md): FETCH_SIZE and
+# WRITE_SIZE collected in separate passes, FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16-byte
+# loads, MI355X_MICROARCH.md "HBM"), per-variant averages weighted by the launch counts of one 50-step object.
+GEMM_TRAFFIC_BYTES_PER_LAUNCH = 2.79e8
 FAMILIES = ["gemm", "attention", "layernorm", "qkv_split", "gemv", "elementwise", "mc_classify", "mc_other"]
 
 
@@ -216,7 +220,9 @@ def main():
         dom = max(("gemm", "attention"), key=lambda k: fam[k]["ms"])
         ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12 if fam[dom]["ms"] > 0 else 0.0
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches": fam[dom]["launches"],
+                           "frac": ach / PEAK_BF16_TFLOPS,
+                           "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if dom == "gemm" else None,
+                           "algorithmic_bytes_per_launch": None, "launches": fam[dom]["launches"],
                            "avg_launch_us": 1000.0 * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
                            "families_ms_per_object": {k: round(v["ms"], 3) for k, v in fam.items()},
                            "attention_tflops": (fam["attention"]["work"] / (fam["attention"]["ms"] * 1e-3) / 1e12

@@ -35,7 +35,11 @@ extern "C" int r3g_emu_mc(const float* grid, int n0, int n1, int n2, double leve
             const int x = (int)(c % cx), y = (int)((c / cx) % cy), z = (int)(c / ((int64_t)cx * cy));
             double v[8];
             int index;
-            flags |= load_corners(grid, nx, ny, x, y, z, level, v, &index);
+            const unsigned f1 = load_corners(grid, nx, ny, x, y, z, level, v, &index);
+            int index2;
+            const unsigned f2 = load_signs(grid, nx, ny, x, y, z, level, &index2);  // the kernel's fast path
+            if (f1 != f2 || index != index2) return -4;
+            flags |= f1;
             const unsigned r = classify_cell(v, index, classic != 0, x, y, z);
             if (r) {
                 rec[b * 256 + sa] = r;
