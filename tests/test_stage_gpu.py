@@ -1,6 +1,6 @@
 """The drop-in stage script end to end on the MI355X: crops in, `<out>/<stem>/<stem>.glb` out, through the hy3dgen
-mirror, libr3g.so, the cleaners and the GLB writer (seeded synthetic full-dims weights -- the mini-dims synthetic field happens to be negative everywhere --, 2 denoising
-steps, 48^3 grid)."""
+mirror, libr3g.so, the cleaners and the GLB writer (seeded synthetic full-dims weights -- the mini-dims synthetic field happens to be negative everywhere --, and
+its 2-step field too --, the reference's 50 denoising steps, 65^3 grid)."""
 import json
 import os
 import subprocess
@@ -24,7 +24,7 @@ def test_stage_script_writes_glbs(tmp_path):
     for i in range(2):
         synthetic_crop(i).save(inp / ("obj__(%d, %d).png" % (i, i)))
     synthetic_crop(5).save(inp / "floor__(1, 1).png")     # must be skipped
-    cfg = {"mini": False, "num_inf_steps_hy": 2, "octree_resolution_hy": 48, "num_chunks_hy": 16000, "seed": 1234567,
+    cfg = {"mini": False, "num_inf_steps_hy": 50, "octree_resolution_hy": 64, "num_chunks_hy": 16000, "seed": 1234567,
            "remesh": False, "input_folder_hy": str(inp), "output_folder_hy": str(out), "use_banana": False,
            "prepped_for_hunyuan": str(tmp_path / "unused"), "jobs_per_gpu": 1, "use_all_available_cuda": False,
            "r3g_weights": "synthetic:{model}"}
