@@ -92,101 +92,12 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
     }
 }
 
-// NW = 4: waves 2(m) x 2(n), 64x64 per wave.  NW = 8: waves 4(m) x 2(n), 32x64 per wave (a wave always owns 64
-// whole columns = one attention head for the EPI_QKV epilogue).  NS = LDS stages (2: wait for everything each k-tile;
-// 3: LDS-DMA of tile t+2 stays in flight across the barrier -- counted vmcnt + raw s_barrier).
-template <int EPI, bool GLDS, int NW, int BIG>
-__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // BIG = 1: 256x256 tile (16 waves of 64x64, or 8 waves of 128x64); BIG = 0: 128x128 (4 waves 64x64 / 8 waves 32x64)
-    constexpr int WN = BIG ? 4 : 2;           // waves along n (64 columns each)
-    constexpr int WM = NW / WN;               // waves along m
-    constexpr int BM = BIG ? 256 : 128, BN = WN * 64;
-    constexpr int MI = BM / WM / 16;          // 16-row sub-tiles per wave
+// Epilogue shared by all GEMM kernels.  acc[j][i]: wave-local sub-tile (n group j of 16 columns, m group i of 16 rows);
+// lane holds row m = m0 + wr*WROWS + i*16 + (lane&15), columns n0 + wc*64 + j*16 + (lane>>4)*4 + {0..3}.
+template <int EPI, int MI, bool SMALLREG>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
+                                              int wc, int lane) {
     constexpr int WROWS = MI * 16;
-    constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
-    // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int rg = p.raster_group < 0 ? (BIG ? 4 : 0) : p.raster_group;   // <0: automatic
-    const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
-    const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
-    const int per_group = rows_all * GN;
-    const int group = wg / per_group;
-    const int within = wg - group * per_group;
-    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
-    const int rowi = within / gn_cur;
-    const int tn = group * GN + (within - rowi * gn_cur);
-    const int batch = rowi / tiles_m;
-    const int tm = rowi - batch * tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const uint16_t* A = p.A + (int64_t)batch * p.strideA;
-    const uint16_t* W = p.W;
-    const int wr = wid / WN, wc = wid % WN;
-
-    f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    auto stage = [&](int t, int slot) {
-        char* base = smem + slot * STAGE_BYTES;
-        stage_tile<GLDS, NW, BM>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
-        stage_tile<GLDS, NW, BN>(W, p.ldw, n0, p.N, t * BK, base + TILE_A, wid, lane, tid);
-    };
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // fragment read offsets (bytes) inside a tile, for the two 32-wide k-steps of a BK=64 tile
-    int offA[MI], offB[4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int rowA = wr * WROWS + i * 16 + (lane & 15);
-        offA[i] = rowA * 128 + ((((lane >> 4)) ^ ((rowA >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rowB = wc * 64 + i * 16 + (lane & 15);
-        offB[i] = rowB * 128 + ((((lane >> 4)) ^ ((rowB >> 1) & 7)) << 4);
-    }
-    // chunk index = kk*4 + (lane>>4); XOR with the row swizzle commutes with adding kk*4 (bit 2 of the chunk)
-    auto load_frags = [&](const char* tile, int kk, bf16x8 (&a)[MI], bf16x8 (&b)[4]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tile + (offA[i] ^ (kk << 6)));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(tile + TILE_A + (offB[i] ^ (kk << 6)));
-    };
-    auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
-    };
-
-    for (int t = 0; t < nk; ++t) {
-        const int slot = t & 1;
-        const char* cur = smem + slot * STAGE_BYTES;
-        if (t + 1 < nk) stage(t + 1, slot ^ 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[MI], b[4];
-            load_frags(cur, kk, a, b);
-            mma(a, b);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
         // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
@@ -293,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (EPI == EPI_RESID_F32) {
         float* X = reinterpret_cast<float*>(p.C) + cbase;
         // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
-        constexpr int JG = BIG ? 1 : 4;
+        constexpr int JG = SMALLREG ? 1 : 4;
 #pragma unroll
         for (int j0 = 0; j0 < 4; j0 += JG) {
             f32x4 old[JG][MI];
@@ -344,6 +255,224 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// NW = 4: waves 2(m) x 2(n), 64x64 per wave.  NW = 8: waves 4(m) x 2(n), 32x64 per wave (a wave always owns 64
+// whole columns = one attention head for the EPI_QKV epilogue).  NS = LDS stages (2: wait for everything each k-tile;
+// 3: LDS-DMA of tile t+2 stays in flight across the barrier -- counted vmcnt + raw s_barrier).
+template <int EPI, bool GLDS, int NW, int BIG>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // BIG = 1: 256x256 tile (16 waves of 64x64, or 8 waves of 128x64); BIG = 0: 128x128 (4 waves 64x64 / 8 waves 32x64)
+    constexpr int WN = BIG ? 4 : 2;           // waves along n (64 columns each)
+    constexpr int WM = NW / WN;               // waves along m
+    constexpr int BM = BIG ? 256 : 128, BN = WN * 64;
+    constexpr int MI = BM / WM / 16;          // 16-row sub-tiles per wave
+    constexpr int WROWS = MI * 16;
+    constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
+    // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int rg = p.raster_group < 0 ? (BIG ? 4 : 0) : p.raster_group;   // <0: automatic
+    const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
+    const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = p.A + (int64_t)batch * p.strideA;
+    const uint16_t* W = p.W;
+    const int wr = wid / WN, wc = wid % WN;
+
+    f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int t, int slot) {
+        char* base = smem + slot * STAGE_BYTES;
+        stage_tile<GLDS, NW, BM>(A, p.lda, m0, p.M, t * BK, base, wid, lane, tid);
+        stage_tile<GLDS, NW, BN>(W, p.ldw, n0, p.N, t * BK, base + TILE_A, wid, lane, tid);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment read offsets (bytes) inside a tile, for the two 32-wide k-steps of a BK=64 tile
+    int offA[MI], offB[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rowA = wr * WROWS + i * 16 + (lane & 15);
+        offA[i] = rowA * 128 + ((((lane >> 4)) ^ ((rowA >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowB = wc * 64 + i * 16 + (lane & 15);
+        offB[i] = rowB * 128 + ((((lane >> 4)) ^ ((rowB >> 1) & 7)) << 4);
+    }
+    // chunk index = kk*4 + (lane>>4); XOR with the row swizzle commutes with adding kk*4 (bit 2 of the chunk)
+    auto load_frags = [&](const char* tile, int kk, bf16x8 (&a)[MI], bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tile + (offA[i] ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(tile + TILE_A + (offB[i] ^ (kk << 6)));
+    };
+    auto mma = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+    };
+
+    for (int t = 0; t < nk; ++t) {
+        const int slot = t & 1;
+        const char* cur = smem + slot * STAGE_BYTES;
+        if (t + 1 < nk) stage(t + 1, slot ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI], b[4];
+            load_frags(cur, kk, a, b);
+            mma(a, b);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    gemm_epilogue<EPI, MI, (BIG != 0)>(p, acc, m0, n0, batch, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Deep-ring variant: 256x256 tile, BK = 32, 4 LDS stages of 32 KiB (A 16 KiB + W 16 KiB), 8 waves of 128x64.
+// Three k-steps of LDS-DMA stay in flight (96 KiB per CU) behind counted s_waitcnt vmcnt + raw s_barrier, and the
+// tile carries twice the flops per staged byte of the 128x128 kernel.  Rows are 64 B (4 chunks); the bank swizzle is
+// chunk ^ F[(row>>2)&3], F = {0,2,3,1}, which makes every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // {0,2,3,1}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, BKD = 32, NSTG = 4, MI = 8;
+    constexpr int TILE = BM * BKD * 2, STAGE = 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int rg = p.raster_group < 0 ? 4 : p.raster_group;
+    const int GN = rg > 0 ? rg : tiles_n;
+    const int rows_all = tiles_m * p.batch;
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = p.A + (int64_t)batch * p.strideA;
+    const uint16_t* W = p.W;
+    const int wr = wid >> 2, wc = wid & 3;
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BKD;
+    // per-lane staging coordinates (2 pieces of A and 2 of W per wave and stage)
+    auto stage = [&](int t, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;  // 1 KiB = 16 rows of 64 B
+            const int row = piece * 16 + (lane >> 2);
+            const int kc = (lane & 3) ^ swz4(row);
+            int ga = m0 + row, gw = n0 + row;
+            ga = ga < p.M ? ga : p.M - 1;
+            gw = gw < p.N ? gw : p.N - 1;
+            const uint16_t* sa = A + (int64_t)ga * p.lda + t * BKD + kc * 8;
+            const uint16_t* sw = W + (int64_t)gw * p.ldw + t * BKD + kc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                             (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sw,
+                                             (__attribute__((address_space(3))) void*)(base + TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    int offA[MI], offB[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wr * 128 + i * 16 + (lane & 15);
+        offA[i] = row * 64 + (((lane >> 4) ^ swz4(row)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wc * 64 + j * 16 + (lane & 15);
+        offB[j] = TILE + row * 64 + (((lane >> 4) ^ swz4(row)) << 4);
+    }
+
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        const char* cur = smem + slot * STAGE;
+        if (t + 3 < nk) stage(t + 3, (slot + 3) & 3);
+        bf16x8 a[MI], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(cur + offB[j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+        // k-step t+1 must have landed; the (up to two) later ones that were already issued may stay in flight
+        const int later = nk - 2 - t;  // k-steps issued beyond t+1
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1) & 3;
+    }
+    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane);
+}
+
+template <int EPI>
+hipError_t launch_deep(const GemmArgs& p, int batch, hipStream_t s) {
+    const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
+    const size_t lds = 4 * 2 * 256 * 32 * 2;  // 128 KiB
+    auto k = gemm_deep_kernel<EPI>;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int EPI, int NW, int BIG>
 hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128;
@@ -380,6 +509,7 @@ hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
         if (EPI != EPI_QKV && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
         else waves = p.N <= 1024 ? 8 : 4;
     }
+    if (waves == 32 && p.K % 32 == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, batch, glds, s);
     if (waves == 9) return launch_cfg<EPI, 8, 1>(p, batch, glds, s);   // 256x256 tile, 8 waves of 128x64
     if (waves == 8) return launch_cfg<EPI, 8, 0>(p, batch, glds, s);
@@ -392,7 +522,7 @@ static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 16) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 

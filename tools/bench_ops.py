@@ -36,7 +36,7 @@ def main():
         w = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
-        for waves, raster in ((4, 0), (8, 0), (9, 4), (0, -1)):
+        for waves, raster in ((4, 0), (8, 0), (9, 4), (32, -1), (32, 0)):
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
             ffi.check(L.r3g_set_option(b"gemm_raster", raster))
             ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
