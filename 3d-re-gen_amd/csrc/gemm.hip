@@ -262,7 +262,8 @@ template <int EPI, bool GLDS, int NW, int BIG>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // BIG = 1: 256x256 tile (16 waves of 64x64, or 8 waves of 128x64); BIG = 0: 128x128 (4 waves 64x64 / 8 waves 32x64)
-    constexpr int WN = BIG ? 4 : 2;           // waves along n (64 columns each)
+    //       BIG = 2: 256x128 tile (8 waves of 64x64): 1/3 less staging traffic than 128x128, finer grid than 256x256
+    constexpr int WN = BIG == 1 ? 4 : 2;      // waves along n (64 columns each)
     constexpr int WM = NW / WN;               // waves along m
     constexpr int BM = BIG ? 256 : 128, BN = WN * 64;
     constexpr int MI = BM / WM / 16;          // 16-row sub-tiles per wave
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int rg = p.raster_group < 0 ? (BIG ? 4 : 0) : p.raster_group;   // <0: automatic
+    const int rg = p.raster_group < 0 ? (BIG == 1 ? 4 : 0) : p.raster_group;   // <0: automatic
     const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, MI, (BIG != 0)>(p, acc, m0, n0, batch, wr, wc, lane);
+    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -475,7 +476,7 @@ hipError_t launch_deep(const GemmArgs& p, int batch, hipStream_t s) {
 
 template <int EPI, int NW, int BIG>
 hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
-    constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128;
+    constexpr int BM = BIG ? 256 : 128, BN = BIG == 1 ? 256 : 128;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
     const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
     auto kt = gemm_kernel<EPI, true, NW, BIG>;
@@ -512,6 +513,7 @@ hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
     if (waves == 32 && p.K % 32 == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, batch, glds, s);
     if (waves == 9) return launch_cfg<EPI, 8, 1>(p, batch, glds, s);   // 256x256 tile, 8 waves of 128x64
+    if (waves == 10) return launch_cfg<EPI, 8, 2>(p, batch, glds, s);  // 256x128 tile, 8 waves of 64x64
     if (waves == 8) return launch_cfg<EPI, 8, 0>(p, batch, glds, s);
     return launch_cfg<EPI, 4, 0>(p, batch, glds, s);
 }
@@ -522,7 +524,7 @@ static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 

@@ -30,13 +30,13 @@ def main():
     L = ffi.lib()
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = []
-    for (M, N, K, epi) in [(8960, 3072, 1024, 0), (8960, 4096, 1024, 1), (8960, 1024, 5120, 3), (8960, 1024, 1024, 3),
+    for (M, N, K, epi) in [(8960, 3072, 1024, 0), (8960, 4096, 1024, 1), (8960, 1024, 5120, 3), (8960, 1024, 1024, 3), (7552, 3072, 1024, 0), (7552, 4096, 1024, 1), (7552, 1024, 5120, 3), (6144, 1024, 4096, 3),
                            (131072, 4096, 1024, 2), (131072, 1024, 4096, 3), (131072, 1024, 1024, 0)]:
         a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         w = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
-        for waves, raster in ((4, 0), (8, 0), (9, 4), (32, -1), (32, 0)):
+        for waves, raster in ((4, 0), (8, 0), (9, 4), (10, 0), (10, 4)):
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
             ffi.check(L.r3g_set_option(b"gemm_raster", raster))
             ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
