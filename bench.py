@@ -153,6 +153,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
     torch.cuda.set_device(local)
+    if world > 1:   # the host-side preprocess of every rank shares the box's cores
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     dist = None
     if world > 1:
         import torch.distributed as dist
