@@ -25,7 +25,16 @@
 #ifndef R3G_DEV
 #define R3G_DEV static inline
 #endif
+#ifndef R3G_HOSTDEV
+#define R3G_HOSTDEV static inline
+#endif
 #include "mc_luts.h"
+
+#if defined(__clang__)
+#define R3G_UNROLL _Pragma("unroll")
+#else
+#define R3G_UNROLL
+#endif
 
 #define R3G_MC_EPS 2.220446049250313e-16
 
@@ -213,9 +222,28 @@ R3G_DEV unsigned owned_mask(int x, int y, int z) {
 }
 
 // Number of vertices this cell creates = distinct owned edges its tiling references.
+// 12 consecutive tiling entries (4 triangles) starting at off + base, packed 4 bits each.  The loads are
+// unconditional (index clamped to the tiling's last entry) so that they are all in flight together: the
+// per-cell loops below then run out of registers instead of waiting for one table byte per iteration.
+R3G_DEV uint64_t load_tri12(int off, int base, int n) {
+    uint64_t packed = 0;
+    R3G_UNROLL
+    for (int j = 0; j < 12; ++j) {
+        const int i = base + j < n ? base + j : n - 1;
+        packed |= (uint64_t)(R3G_MC_TRI[off + i] & 0xF) << (4 * j);
+    }
+    return packed;
+}
+
 R3G_DEV int count_new_vertices(const Tiling& t, unsigned owned) {
     unsigned seen = 0;
-    for (int i = 0; i < 3 * t.nt; ++i) seen |= 1u << R3G_MC_TRI[t.off + i];
+    const int n = 3 * t.nt;
+    for (int base = 0; base < n; base += 12) {
+        const uint64_t tri = load_tri12(t.off, base, n);
+        R3G_UNROLL
+        for (int j = 0; j < 12; ++j)
+            if (base + j < n) seen |= 1u << (unsigned)((tri >> (4 * j)) & 0xF);
+    }
     seen &= owned;
 #if defined(__HIP_DEVICE_COMPILE__)
     return __popc(seen);
@@ -239,14 +267,10 @@ R3G_DEV int64_t edge_slot(int e, int x, int y, int z, int nx, int ny) {
 
 // Interpolated position (x, y, z order = array axes 2, 1, 0) of the vertex on local edge e,
 // in double, exactly as the sequential kernel: inverse-|value| weights, then x + fx/ff.
-R3G_DEV void edge_vertex(const double* v, int e, int x, int y, int z, double* out) {
+R3G_DEV void edge_vertex_ab(double a, double b, int e, int x, int y, int z, double* out) {
     const int dx1 = R3G_MC_EDGE_DX[e][0], dx2 = R3G_MC_EDGE_DX[e][1];
     const int dy1 = R3G_MC_EDGE_DY[e][0], dy2 = R3G_MC_EDGE_DY[e][1];
     const int dz1 = R3G_MC_EDGE_DZ[e][0], dz2 = R3G_MC_EDGE_DZ[e][1];
-    // corner (dz,dy,dx) -> Lewiner corner number (2<->3 and 6<->7 swapped w.r.t. the bit order)
-    const int REMAP[8] = {0, 1, 3, 2, 4, 5, 7, 6};
-    const double a = v[REMAP[dz1 * 4 + dy1 * 2 + dx1]];
-    const double b = v[REMAP[dz2 * 4 + dy2 * 2 + dx2]];
     const double w1 = 1.0 / (R3G_MC_EPS + dabs(a));
     const double w2 = 1.0 / (R3G_MC_EPS + dabs(b));
     double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
@@ -263,6 +287,7 @@ R3G_DEV void center_vertex(const double* v, int x, int y, int z, double* out) {
     const double DY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
     const double DZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
     double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
+    R3G_UNROLL
     for (int k = 0; k < 8; ++k) {
         const double w = 1.0 / (R3G_MC_EPS + dabs(v[k]));
         fx += DX[k] * w;
@@ -276,7 +301,7 @@ R3G_DEV void center_vertex(const double* v, int x, int y, int z, double* out) {
 }
 
 // Output transform of one vertex.  pos = kernel (x,y,z); the wrapper returns (z,y,x) float32.
-// With xf != null the upstream hy3dgen rescale is applied on the float32 value in double:
+// With use_xf the upstream hy3dgen rescale is applied on the float32 value in double:
 //   v / grid_size * bbox_size + bbox_min   (surface_extractors.MCSurfaceExtractor.run)
 struct Xform {
     double grid_size[3];  // per OUTPUT column (axis0, axis1, axis2)
@@ -284,12 +309,12 @@ struct Xform {
     double bbox_min[3];
 };
 
-R3G_DEV void store_vertex(float* dst, const double* pos, const Xform* xf) {
+R3G_DEV void store_vertex(float* dst, const double* pos, const Xform& xf, bool use_xf) {
     const float o0 = (float)pos[2], o1 = (float)pos[1], o2 = (float)pos[0];
-    if (xf) {
-        dst[0] = (float)((double)o0 / xf->grid_size[0] * xf->bbox_size[0] + xf->bbox_min[0]);
-        dst[1] = (float)((double)o1 / xf->grid_size[1] * xf->bbox_size[1] + xf->bbox_min[1]);
-        dst[2] = (float)((double)o2 / xf->grid_size[2] * xf->bbox_size[2] + xf->bbox_min[2]);
+    if (use_xf) {
+        dst[0] = (float)((double)o0 / xf.grid_size[0] * xf.bbox_size[0] + xf.bbox_min[0]);
+        dst[1] = (float)((double)o1 / xf.grid_size[1] * xf.bbox_size[1] + xf.bbox_min[1]);
+        dst[2] = (float)((double)o2 / xf.grid_size[2] * xf.bbox_size[2] + xf.bbox_min[2]);
     } else {
         dst[0] = o0;
         dst[1] = o1;
@@ -318,6 +343,7 @@ R3G_DEV unsigned load_corners(const float* g, int nx, int ny, int x, int y, int 
     f[4] = p[sz]; f[5] = p[sz + 1]; f[6] = p[sz + sy + 1]; f[7] = p[sz + sy];
     unsigned flags = 0;
     int idx = 0;
+    R3G_UNROLL
     for (int k = 0; k < 8; ++k) {
         const double d = (double)f[k];
         if (d <= level) flags |= R3G_MC_FLAG_LE;
@@ -361,24 +387,63 @@ R3G_DEV unsigned classify_cell(const double* v, int index, bool classic, int x, 
     return (unsigned)t.off | ((unsigned)t.nt << 16) | ((unsigned)nv << 20);
 }
 
-R3G_DEV void emit_cell_vertices(unsigned rec, unsigned vbase, const double* v, int x, int y, int z,
-                                int nx, int ny, int32_t* etab, float* verts, const Xform* xf) {
+// Float-domain form of the sign test used by the row kernel: with lo = the largest float <= level,
+// (double)f > level  <=>  f > lo   and   (double)f <= level  <=>  f <= lo   (no float lies in (lo, level]),
+// and (double)f == level  <=>  level is a float and f == lo.
+R3G_HOSTDEV void level_floor(double level, float* lo, int* exact) {
+    float lf = (float)level;
+    if ((double)lf > level) {
+        // step to the next float towards -inf (written out: no libm in device code)
+        union { float f; uint32_t u; } c;
+        c.f = lf;
+        if (lf > 0.0f) c.u -= 1u;
+        else if (lf == 0.0f) c.u = 0x80000001u;
+        else c.u += 1u;
+        lf = c.f;
+    }
+    *lo = lf;
+    *exact = ((double)lf == level) ? 1 : 0;
+}
+
+R3G_DEV bool node_greater(float f, float lo, int exact, unsigned* flags) {
+    const bool gt = f > lo;
+    if (!gt) *flags |= (f <= lo) ? R3G_MC_FLAG_LE : R3G_MC_FLAG_NAN;
+    if (gt || (exact && f == lo)) *flags |= R3G_MC_FLAG_GE;
+    return gt;
+}
+
+// Vertices of one active cell.  Edge endpoints are read from the grid per edge (two L1-resident
+// floats) instead of indexing a corner array dynamically, which would live in scratch memory.
+R3G_DEV void emit_cell_vertices(unsigned rec, unsigned vbase, const float* g, double level, int x, int y, int z,
+                                int nx, int ny, int32_t* etab, float* verts, const Xform& xf, bool use_xf) {
     const int off = (int)(rec & 0xFFFFu), n = 3 * (int)((rec >> 16) & 0xFu);
     const unsigned owned = owned_mask(x, y, z);
+    const int64_t sy = nx, sz = (int64_t)nx * ny;
+    const float* p = g + (int64_t)z * sz + (int64_t)y * sy + x;
     unsigned seen = 0, id = vbase;
+    uint64_t tri = 0;
     for (int i = 0; i < n; ++i) {
-        const int e = R3G_MC_TRI[off + i];
+        if (i % 12 == 0) tri = load_tri12(off, i, n);
+        const int e = (int)((tri >> (4 * (i % 12))) & 0xF);
         const unsigned bit = 1u << e;
         if ((seen & bit) || !(owned & bit)) continue;
         seen |= bit;
         double pos[3];
         if (e == 12) {
+            double v[8];
+            int index;
+            load_corners(g, nx, ny, x, y, z, level, v, &index);
             center_vertex(v, x, y, z, pos);
         } else {
-            edge_vertex(v, e, x, y, z, pos);
+            const int dx1 = R3G_MC_EDGE_DX[e][0], dx2 = R3G_MC_EDGE_DX[e][1];
+            const int dy1 = R3G_MC_EDGE_DY[e][0], dy2 = R3G_MC_EDGE_DY[e][1];
+            const int dz1 = R3G_MC_EDGE_DZ[e][0], dz2 = R3G_MC_EDGE_DZ[e][1];
+            const double a = (double)p[dz1 * sz + dy1 * sy + dx1] - level;
+            const double b = (double)p[dz2 * sz + dy2 * sy + dx2] - level;
+            edge_vertex_ab(a, b, e, x, y, z, pos);
             etab[edge_slot(e, x, y, z, nx, ny)] = (int32_t)id;
         }
-        store_vertex(verts + 3 * (int64_t)id, pos, xf);
+        store_vertex(verts + 3 * (int64_t)id, pos, xf, use_xf);
         ++id;
     }
 }
@@ -389,10 +454,13 @@ R3G_DEV void emit_cell_faces(unsigned rec, unsigned vbase, unsigned tbase, int x
     const unsigned owned = owned_mask(x, y, z);
     unsigned seen = 0, next = 0;
     unsigned long long ranks = 0;  // 4 bits per local edge: rank among this cell's new vertices
+    uint64_t packed = 0;
     for (int t = 0; t < nt; ++t) {
         int32_t tri[3];
+        if (t % 4 == 0) packed = load_tri12(off, 3 * t, 3 * nt);
+        R3G_UNROLL
         for (int j = 0; j < 3; ++j) {
-            const int e = R3G_MC_TRI[off + 3 * t + j];
+            const int e = (int)((packed >> (4 * (3 * (t % 4) + j))) & 0xF);
             const unsigned bit = 1u << e;
             if (owned & bit) {
                 if (!(seen & bit)) {

@@ -101,7 +101,7 @@ int r3g_mc_count(r3g_ctx* ctx, const float* d_grid, int n0, int n1, int n2, doub
     if (rc) return rc;
     hipError_t e = mc_count_launch(d_grid, n0, n1, n2, level, use_classic, c->mc_ws, lay, s);
     if (e != hipSuccess) return hip_fail(e, "mc_count_launch");
-    e = hipMemcpyAsync(c->h_small, c->mc_ws + lay.off_small, 32, hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(c->h_small, c->mc_ws + lay.off_small, 64, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(mc totals)");
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(mc count)");
@@ -115,6 +115,7 @@ int r3g_mc_count(r3g_ctx* ctx, const float* d_grid, int n0, int n1, int n2, doub
         return fail(R3G_ERR_LEVEL_RANGE, "Surface level must be within volume data range.");
     if (nv == 0) return fail(R3G_ERR_NO_SURFACE, "No surface found at the given iso value.");
     c->mc_lay = lay;
+    c->mc_lay.nnz = (uint32_t)((const unsigned long long*)c->h_small)[4];
     c->mc_grid = d_grid;
     c->mc_n[0] = n0; c->mc_n[1] = n1; c->mc_n[2] = n2;
     c->mc_level = level;

@@ -39,6 +39,16 @@ extern "C" int r3g_emu_mc(const float* grid, int n0, int n1, int n2, double leve
             int index2;
             const unsigned f2 = load_signs(grid, nx, ny, x, y, z, level, &index2);  // the kernel's fast path
             if (f1 != f2 || index != index2) return -4;
+            {   // the row kernel's float-domain sign test must agree as well
+                float lo; int exact;
+                level_floor(level, &lo, &exact);
+                const int64_t sy = nx, sz = (int64_t)nx * ny;
+                const float* p = grid + z * sz + y * sy + x;
+                const float f[8] = {p[0], p[1], p[sy + 1], p[sy], p[sz], p[sz + 1], p[sz + sy + 1], p[sz + sy]};
+                unsigned f3 = 0; int index3 = 0;
+                for (int k = 0; k < 8; ++k) if (node_greater(f[k], lo, exact, &f3)) index3 |= 1 << k;
+                if (f3 != f1 || index3 != index) return -5;
+            }
             flags |= f1;
             const unsigned r = classify_cell(v, index, classic != 0, x, y, z);
             if (r) {
@@ -67,9 +77,7 @@ extern "C" int r3g_emu_mc(const float* grid, int n0, int n1, int n2, double leve
             const uint32_t r = rec[b * 256 + a], l = loc[b * 256 + a];
             const int64_t c = b * 256 + (l & 0xFF);
             const int x = (int)(c % cx), y = (int)((c / cx) % cy), z = (int)(c / ((int64_t)cx * cy));
-            double v[8]; int index;
-            load_corners(grid, nx, ny, x, y, z, level, v, &index);
-            emit_cell_vertices(r, offV[b] + ((l >> 8) & 0xFFF), v, x, y, z, nx, ny, etab.data(), verts, xf9 ? &xf : nullptr);
+            emit_cell_vertices(r, offV[b] + ((l >> 8) & 0xFFF), grid, level, x, y, z, nx, ny, etab.data(), verts, xf, xf9 != nullptr);
         }
     // pass 4: faces
     int bad = 0;

@@ -33,14 +33,21 @@ def blob(n):
     return f.contiguous()
 
 
+def dot(n):
+    """almost empty grid: one small sphere -> the classify pass is a pure stream"""
+    ax = torch.linspace(-1, 1, n)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    return (0.06 - torch.sqrt(X ** 2 + Y ** 2 + Z ** 2)).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--field", default="blob", choices=["blob", "noise"])
+    ap.add_argument("--field", default="blob", choices=["blob", "noise", "dot"])
     ap.add_argument("--n", type=int, default=257)
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     from r3g import mc
-    g = (blob(a.n) if a.field == "blob" else field(a.n)).cuda()
+    g = {"blob": blob, "noise": field, "dot": dot}[a.field](a.n).cuda()
     for _ in range(3):
         v, f = mc.extract_mesh(g)
     torch.cuda.synchronize()
