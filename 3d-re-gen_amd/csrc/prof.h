@@ -5,7 +5,7 @@
 
 namespace r3g {
 
-enum ProfCat { PC_GEMM = 0, PC_ATTN, PC_LAYERNORM, PC_QKV_SPLIT, PC_GEMV, PC_ELEMWISE, PC_MC_CLASSIFY, PC_MC_OTHER, PC_COUNT };
+enum ProfCat { PC_GEMM = 0, PC_ATTN, PC_LAYERNORM, PC_QKV_SPLIT, PC_GEMV, PC_ELEMWISE, PC_MC_CLASSIFY, PC_MC_OTHER, PC_MESH, PC_COUNT };
 
 // RAII bracket around one kernel launch.  `work` = algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels).
 struct ProfScope {

@@ -8,6 +8,7 @@
 
 #include "../../include/r3g.h"
 #include "r3g_ctx.h"
+#include "mesh_kernels.h"
 
 namespace r3g {
 static thread_local char g_err[512] = "";
@@ -81,6 +82,7 @@ void r3g_destroy(r3g_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     (void)hipSetDevice(c->device);
     if (c->mc_ws) (void)hipFree(c->mc_ws);
+    if (c->mesh_ws) (void)hipFree(c->mesh_ws);
     if (c->h_small) (void)hipHostFree(c->h_small);
     c->release_model();
     delete c;
@@ -132,6 +134,55 @@ int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xf
                                   d_verts, d_faces, xform, reverse_faces, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "mc_emit_launch");
     return R3G_OK;
+}
+
+// ---- mesh cleaners -------------------------------------------------------------------------------------------
+static int mesh_args(const char* who, r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces,
+                     int64_t* n_faces) {
+    if (!ctx || !n_verts || !n_faces) return fail(R3G_ERR_INVALID, "%s: null argument", who);
+    if (*n_verts < 0 || *n_faces < 0 || *n_verts >= (1ll << 31) || *n_faces >= (1ll << 30))
+        return fail(R3G_ERR_INVALID, "%s: mesh size out of range", who);
+    if ((*n_verts && !d_verts) || (*n_faces && !d_faces)) return fail(R3G_ERR_INVALID, "%s: null buffer", who);
+    return R3G_OK;
+}
+
+int r3g_mesh_remove_floaters(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                             double min_ratio, void* stream) {
+    int rc = mesh_args("r3g_mesh_remove_floaters", ctx, d_verts, n_verts, d_faces, n_faces);
+    if (rc) return rc;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    rc = c->reserve(&c->mesh_ws, &c->mesh_ws_bytes, mesh_workspace_bytes(*n_verts, *n_faces, 0), "hipMalloc(mesh workspace)");
+    if (rc) return rc;
+    hipError_t e = mesh_remove_floaters(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
+                                        n_faces, min_ratio, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_remove_floaters");
+}
+
+int r3g_mesh_remove_degenerate(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                               void* stream) {
+    int rc = mesh_args("r3g_mesh_remove_degenerate", ctx, d_verts, n_verts, d_faces, n_faces);
+    if (rc) return rc;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    rc = c->reserve(&c->mesh_ws, &c->mesh_ws_bytes, mesh_workspace_bytes(*n_verts, *n_faces, 0), "hipMalloc(mesh workspace)");
+    if (rc) return rc;
+    hipError_t e = mesh_remove_degenerate(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
+                                          n_faces, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_remove_degenerate");
+}
+
+int r3g_mesh_reduce_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                          int64_t max_faces, void* stream) {
+    int rc = mesh_args("r3g_mesh_reduce_faces", ctx, d_verts, n_verts, d_faces, n_faces);
+    if (rc) return rc;
+    if (max_faces < 1 || max_faces > 200000000) return fail(R3G_ERR_INVALID, "r3g_mesh_reduce_faces: max_faces out of range");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const int64_t r = mesh_reduce_initial_res(max_faces);
+    rc = c->reserve(&c->mesh_ws, &c->mesh_ws_bytes, mesh_workspace_bytes(*n_verts, *n_faces, r * r * r),
+                    "hipMalloc(mesh workspace)");
+    if (rc) return rc;
+    hipError_t e = mesh_reduce_faces(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
+                                     n_faces, max_faces, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_reduce_faces");
 }
 
 }  // extern "C"

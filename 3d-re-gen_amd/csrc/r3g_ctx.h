@@ -24,6 +24,9 @@ struct Ctx {
     int mc_n[3] = {0, 0, 0};
     double mc_level = 0.0;
     bool mc_counted = false;
+    // mesh cleaners
+    char* mesh_ws = nullptr;
+    size_t mesh_ws_bytes = 0;
 
     int reserve(char** buf, size_t* have, size_t need, const char* what);
     void* model = nullptr;  // r3g::Model (model.cpp)

@@ -163,7 +163,7 @@ class Hunyuan3DDiTPipeline:
                 print("[hy3dgen] surface extraction failed: %s" % e)
                 return [None]
             if output_type == "trimesh":
-                return [Mesh(v.cpu().numpy(), f.cpu().numpy())]
+                return [Mesh.from_device(v, f)]   # stays in HBM for the cleaners; host arrays on first read
             return [(v, f)]
 
 

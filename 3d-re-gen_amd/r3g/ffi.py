@@ -36,6 +36,9 @@ SYMBOLS = {
     "r3g_destroy": (None, [_P]),
     "r3g_mc_count": (_I, [_P, _P, _I, _I, _I, _D, _I, _I64P, _I64P, _P]),
     "r3g_mc_emit": (_I, [_P, _P, _P, _P, _I, _P]),
+    "r3g_mesh_remove_floaters": (_I, [_P, _P, _I64P, _P, _I64P, _D, _P]),
+    "r3g_mesh_remove_degenerate": (_I, [_P, _P, _I64P, _P, _I64P, _P]),
+    "r3g_mesh_reduce_faces": (_I, [_P, _P, _I64P, _P, _I64P, ctypes.c_int64, _P]),
     "r3g_model_create": (_I, [_P, _P]),
     "r3g_model_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
     "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),

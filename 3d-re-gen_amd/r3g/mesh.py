@@ -14,21 +14,86 @@ import numpy as np
 
 
 class Mesh:
+    """Host arrays (float64 vertices, int64 faces, as trimesh holds them) and/or device buffers (float32 / int32
+    torch CUDA tensors, as marching cubes and the GPU cleaners produce them).  The host arrays of a device-born mesh
+    are only downloaded when something reads `.vertices` / `.faces`; assigning either drops the device copy."""
+
     def __init__(self, vertices=None, faces=None, vertex_colors=None, process=True):
-        self.vertices = np.zeros((0, 3), np.float64) if vertices is None else np.asarray(vertices, np.float64).reshape(-1, 3)
-        self.faces = np.zeros((0, 3), np.int64) if faces is None else np.asarray(faces, np.int64).reshape(-1, 3)
+        self._dv = self._df = None
+        self._v = np.zeros((0, 3), np.float64) if vertices is None else np.asarray(vertices, np.float64).reshape(-1, 3)
+        self._f = np.zeros((0, 3), np.int64) if faces is None else np.asarray(faces, np.int64).reshape(-1, 3)
         self.vertex_colors = None if vertex_colors is None else np.asarray(vertex_colors, np.uint8)
         self.metadata = {}
+
+    @classmethod
+    def from_device(cls, verts, faces, metadata=None):
+        """verts float32 [V,3], faces int32 [F,3] torch CUDA tensors (kept, not copied)"""
+        m = cls.__new__(cls)
+        m._v = m._f = None
+        m._dv, m._df = verts, faces
+        m.vertex_colors = None
+        m.metadata = dict(metadata or {})
+        return m
+
+    # -- storage ---------------------------------------------------------------------------------
+    @property
+    def vertices(self):
+        if self._v is None:
+            self._v = self._dv.detach().cpu().numpy().astype(np.float64).reshape(-1, 3)
+        return self._v
+
+    @vertices.setter
+    def vertices(self, value):
+        self._host()
+        self._v = np.asarray(value, np.float64).reshape(-1, 3)
+        self._dv = self._df = None
+
+    @property
+    def faces(self):
+        if self._f is None:
+            self._f = self._df.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
+        return self._f
+
+    @faces.setter
+    def faces(self, value):
+        self._host()
+        self._f = np.asarray(value, np.int64).reshape(-1, 3)
+        self._dv = self._df = None
+
+    def _host(self):
+        return self.vertices, self.faces
+
+    @property
+    def n_vertices(self):
+        return int(self._v.shape[0] if self._v is not None else self._dv.shape[0])
+
+    @property
+    def n_faces(self):
+        return int(self._f.shape[0] if self._f is not None else self._df.shape[0])
+
+    def device_buffers(self, device=None):
+        """(verts float32 [V,3], faces int32 [F,3]) on the GPU; uploads the host arrays when there is no device copy"""
+        if self._dv is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise RuntimeError("Mesh.device_buffers: no GPU (the mesh cleaners have no CPU path)")
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            self._dv = torch.from_numpy(np.ascontiguousarray(self._v, np.float32)).to(dev)
+            self._df = torch.from_numpy(np.ascontiguousarray(self._f, np.int32)).to(dev)
+        return self._dv, self._df
 
     # -- trimesh-like surface ------------------------------------------------------------------
     @property
     def is_empty(self):
-        return len(self.vertices) == 0 or len(self.faces) == 0
+        return self.n_vertices == 0 or self.n_faces == 0
 
     def copy(self):
-        m = Mesh(self.vertices.copy(), self.faces.copy(),
-                 None if self.vertex_colors is None else self.vertex_colors.copy())
-        m.metadata = dict(self.metadata)
+        if self._v is None:
+            m = Mesh.from_device(self._dv.clone(), self._df.clone(), self.metadata)
+        else:
+            m = Mesh(self.vertices.copy(), self.faces.copy())
+            m.metadata = dict(self.metadata)
+        m.vertex_colors = None if self.vertex_colors is None else self.vertex_colors.copy()
         return m
 
     def update_vertices(self, mask):

@@ -1,0 +1,44 @@
+"""Mesh cleaners on device buffers (include/r3g.h "mesh cleaners"): the GPU side of
+hy3dgen.shapegen.postprocessors.  Inputs are torch CUDA tensors verts float32 [V,3] / faces int32 [F,3]; every
+function returns new (verts, faces) tensors holding the compacted result (the inputs are not modified)."""
+import ctypes
+
+import torch
+
+from . import ffi
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _prepare(verts, faces):
+    if not (verts.is_cuda and faces.is_cuda):
+        raise ValueError("mesh buffers must live on the GPU (there is no CPU path)")
+    v = verts.detach().to(torch.float32).contiguous().clone()
+    f = faces.detach().to(torch.int32).contiguous().clone()
+    if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+        raise ValueError("expected verts [V,3] and faces [F,3]")
+    return v, f
+
+
+def _run(fn, verts, faces, *extra):
+    v, f = _prepare(verts, faces)
+    nv, nf = ctypes.c_int64(v.shape[0]), ctypes.c_int64(f.shape[0])
+    ctx = ffi.context(v.device.index or 0)
+    with torch.cuda.device(v.device):
+        ffi.check(fn(ctx, ctypes.c_void_p(v.data_ptr()), ctypes.byref(nv), ctypes.c_void_p(f.data_ptr()),
+                     ctypes.byref(nf), *extra, _stream_ptr()))
+    return v[:nv.value], f[:nf.value]
+
+
+def remove_floaters(verts, faces, min_ratio=0.005):
+    return _run(ffi.lib().r3g_mesh_remove_floaters, verts, faces, ctypes.c_double(min_ratio))
+
+
+def remove_degenerate(verts, faces):
+    return _run(ffi.lib().r3g_mesh_remove_degenerate, verts, faces)
+
+
+def reduce_faces(verts, faces, max_faces=40000):
+    return _run(ffi.lib().r3g_mesh_reduce_faces, verts, faces, ctypes.c_int64(int(max_faces)))

@@ -133,10 +133,10 @@ def process_image(image_path, shapegen, texgen, cleaners, output_dir, config):
         raise RuntimeError("surface extraction produced no mesh")
     if config.get("remesh", False):
         mesh = clean_and_validate_mesh(mesh, target_face_count=config.get("remesh_target_num_faces", 30000))
-    print("Initial mesh has %d vertices and %d faces." % (len(mesh.vertices), len(mesh.faces)))
+    print("Initial mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
     for cleaner in cleaners:
         mesh = cleaner(mesh)
-    print("Cleaned mesh has %d vertices and %d faces." % (len(mesh.vertices), len(mesh.faces)))
+    print("Cleaned mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
     mesh = texgen(mesh, image=image)
     out_dir = os.path.join(output_dir, base)
     os.makedirs(out_dir, exist_ok=True)

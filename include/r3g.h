@@ -72,6 +72,28 @@ int r3g_mc_count(r3g_ctx* ctx, const float* d_grid, int n0, int n1, int n2, doub
 int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xform, int reverse_faces,
                 void* stream);
 
+/* ---- mesh cleaners ------------------------------------------------------
+ * Replace `mesh = FloaterRemover()(mesh); mesh = DegenerateFaceRemover()(mesh); mesh = FaceReducer()(mesh)`
+ * (reference src/2d_to_3d_models/run.py:93-94; upstream hy3dgen/shapegen/postprocessors.py runs pymeshlab on
+ * one CPU thread) on the device buffers r3g_mc_emit filled: d_verts float32 [*n_verts][3], d_faces int32
+ * [*n_faces][3].  Each call compacts both arrays in place (survivors keep their order), stores the new sizes in
+ * *n_verts / *n_faces and synchronises `stream`.
+ *   remove_floaters  : drops every connected component (vertices joined by a face) with fewer faces than
+ *                      max(1, ceil(min_ratio * faces of the largest component)), then unreferenced vertices.
+ *   remove_degenerate: drops faces with a repeated vertex index, then unreferenced vertices.
+ *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise vertex clustering on a uniform grid over the
+ *                      bounding box (first resolution floor(sqrt(max_faces / 2.2)), shrunk by 0.9 until the face
+ *                      budget holds, at most 24 times): a cluster's vertex is the mean of its members, faces
+ *                      that collapse or repeat an earlier face's vertex set are dropped.  (Upstream uses quadric
+ *                      edge collapse: equivalence with it is geometric, not index-wise.)
+ * The results are pure functions of the input: oracle/mesh_clean.py reproduces them bit for bit. */
+int r3g_mesh_remove_floaters(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                             double min_ratio, void* stream);
+int r3g_mesh_remove_degenerate(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                               void* stream);
+int r3g_mesh_reduce_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                          int64_t max_faces, void* stream);
+
 /* ---- shape model (DiT + ShapeVAE + DINOv2 conditioner) -----------------------------------------
  * Replaces the modules `Hunyuan3DDiTFlowMatchingPipeline.from_pretrained` instantiates from the
  * checkpoint's config.yaml (reference call sites src/2d_to_3d_models/run.py:122-124,204-206;
@@ -145,8 +167,8 @@ int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t l
 int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
                      int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream);
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).  Families, in order:
- * 0 gemm, 1 attention, 2 layernorm, 3 qkv_split, 4 gemv, 5 elementwise, 6 mc_classify, 7 mc_other (n >= 8).
- * work = algorithmic FLOPs (0,1,4) / bytes (6) summed over the launches since r3g_prof_enable(1). */
+ * 0 gemm, 1 attention, 2 layernorm, 3 qkv_split, 4 gemv, 5 elementwise, 6 mc_classify, 7 mc_other, 8 mesh
+ * cleaners (n >= 9).  work = algorithmic FLOPs (0,1,4) / bytes (6,8) summed over the launches since r3g_prof_enable(1). */
 int r3g_prof_enable(int on);
 int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
 /* A/B switches for tests and ablations (defaults 1): "fuse_qkv" (QKV split/norm/transpose in the projection

@@ -61,24 +61,33 @@ def test_mesh_glb_roundtrip(tmp_path):
     assert data[:4] == b"glTF" and len(data) % 4 == 0
 
 
-def test_cleaners():
-    from hy3dgen.shapegen import DegenerateFaceRemover, FaceReducer, FloaterRemover
-    from oracle import mc
+def test_cleaner_oracle():
+    """the numpy restatement of the cleaners (oracle/mesh_clean.py) behaves as the three classes are meant to"""
+    from oracle import mc, mesh_clean
     from mc_volumes import golden_volume
     vol, level = golden_volume("A")
     v, f = mc.hy3d_mesh(vol, level)
-    from r3g.mesh import Mesh
-    big = Mesh(v, f)
+    v = v.astype(np.float32)
     # add a floater: one far-away triangle, and a degenerate face
-    m = Mesh(np.concatenate([v, [[5, 5, 5], [5, 5, 5.1], [5, 5.1, 5]]]), np.concatenate([f, [[len(v), len(v) + 1, len(v) + 2]],
-                                                                                        [[0, 0, 1]]]))
-    m2 = DegenerateFaceRemover()(FloaterRemover()(m))
-    assert len(m2.faces) == len(big.faces) and len(m2.vertices) == len(big.vertices)
-    r = FaceReducer()(big, max_facenum=3000)
-    assert 0 < len(r.faces) <= 3000
-    # still roughly the same sphere
-    rad = np.linalg.norm(r.vertices, axis=1)
-    assert abs(rad.mean() - np.linalg.norm(big.vertices, axis=1).mean()) < 0.05
+    v2 = np.concatenate([v, np.array([[5, 5, 5], [5, 5, 5.1], [5, 5.1, 5]], np.float32)])
+    f2 = np.concatenate([f, [[len(v), len(v) + 1, len(v) + 2]], [[0, 0, 1]]])
+    a, b = mesh_clean.remove_floaters(v2, f2)
+    a, b = mesh_clean.remove_degenerate(a, b)
+    assert np.array_equal(a, v) and np.array_equal(b, f)
+    rv, rf = mesh_clean.reduce_faces(v, f, max_faces=3000)
+    assert 0 < len(rf) <= 3000 and rf.max() == len(rv) - 1
+    assert abs(np.linalg.norm(rv, axis=1).mean() - np.linalg.norm(v, axis=1).mean()) < 0.05
+    same_v, same_f = mesh_clean.reduce_faces(v, f, max_faces=len(f))
+    assert np.array_equal(same_v, v) and np.array_equal(same_f, f)
+
+
+def test_mesh_host_device_views():
+    from r3g.mesh import Mesh
+    m = Mesh(np.zeros((3, 3)), [[0, 1, 2]])
+    assert m.n_vertices == 3 and m.n_faces == 1 and not m.is_empty
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.device_buffers()      # the cleaners have no CPU path
 
 
 def test_preprocess_product_equals_oracle():

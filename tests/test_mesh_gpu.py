@@ -1,0 +1,114 @@
+"""GPU parity of the mesh cleaners (include/r3g.h "mesh cleaners") against the numpy restatement
+oracle/mesh_clean.py: faces AND float32 vertices bit-exact, on marching-cubes meshes with floaters, on triangle
+soups with degenerate and duplicate faces, and on the empty / tiny edge cases."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mc_mesh(n=65, seed=0, floaters=3):
+    """smooth blob + a few small far-away spheres, meshed by the product marching cubes"""
+    from r3g import mc
+    ax = torch.linspace(-1, 1, n)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    rng = np.random.default_rng(seed)
+    f = torch.full((n, n, n), -1.0)
+    for _ in range(4):
+        c = rng.uniform(-0.3, 0.3, 3)
+        f = torch.maximum(f, float(rng.uniform(0.25, 0.45)) - torch.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2))
+    for _ in range(floaters):
+        c = rng.uniform(0.75, 0.9, 3) * rng.choice([-1, 1], 3)
+        f = torch.maximum(f, 0.05 - torch.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2))
+    v, fa = mc.extract_mesh(f.cuda().contiguous(), 0.0, 1.01, n - 1)
+    return v, fa
+
+
+def _soup(nv, nf, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((nv, 3)).astype(np.float32)
+    f = rng.integers(0, nv, (nf, 3)).astype(np.int32)
+    f[::7, 1] = f[::7, 0]                      # degenerate faces
+    f[5::11] = f[4::11][:len(f[5::11])]        # exact duplicates
+    f[9::13] = f[8::13][:len(f[9::13]), ::-1]  # same vertex set, other winding
+    return torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda()
+
+
+def _same(got, want):
+    gv, gf = got[0].cpu().numpy(), got[1].cpu().numpy()
+    wv, wf = want
+    assert gf.shape == wf.shape and np.array_equal(gf, wf)
+    assert gv.shape == wv.shape and np.array_equal(gv.view(np.uint32), wv.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_floaters_and_degenerate_on_mc_mesh(seed):
+    from oracle import mesh_clean
+    from r3g import meshops
+    v, f = _mc_mesh(65, seed)
+    hv, hf = v.cpu().numpy(), f.cpu().numpy()
+    got = meshops.remove_floaters(v, f, 0.02)
+    want = mesh_clean.remove_floaters(hv, hf, 0.02)
+    assert len(want[1]) < len(hf)                         # the small spheres went away
+    _same(got, want)
+    _same(meshops.remove_floaters(v, f), mesh_clean.remove_floaters(hv, hf))             # default ratio
+    _same(meshops.remove_floaters(v, f, 0.0), mesh_clean.remove_floaters(hv, hf, 0.0))   # keeps everything
+    _same(meshops.remove_degenerate(*got), mesh_clean.remove_degenerate(*want))
+
+
+@pytest.mark.parametrize("nv,nf,seed", [(50, 400, 0), (5000, 20000, 1), (3, 1, 2)])
+def test_soup(nv, nf, seed):
+    from oracle import mesh_clean
+    from r3g import meshops
+    v, f = _soup(nv, nf, seed)
+    hv, hf = v.cpu().numpy(), f.cpu().numpy()
+    _same(meshops.remove_degenerate(v, f), mesh_clean.remove_degenerate(hv, hf))
+    _same(meshops.remove_floaters(v, f, 0.3), mesh_clean.remove_floaters(hv, hf, 0.3))
+    _same(meshops.reduce_faces(v, f, max(1, nf // 10)), mesh_clean.reduce_faces(hv, hf, max(1, nf // 10)))
+
+
+@pytest.mark.parametrize("n,budget", [(65, 3000), (129, 40000), (129, 500)])
+def test_reduce_on_mc_mesh(n, budget):
+    from oracle import mesh_clean
+    from r3g import meshops
+    v, f = _mc_mesh(n, 3, floaters=0)
+    want = mesh_clean.reduce_faces(v.cpu().numpy(), f.cpu().numpy(), budget)
+    got = meshops.reduce_faces(v, f, budget)
+    assert 0 < len(want[1]) <= budget
+    _same(got, want)
+    again = meshops.reduce_faces(*got, budget)            # already within budget: untouched
+    _same(again, want)
+
+
+def test_inputs_untouched_and_empty():
+    from r3g import meshops
+    v, f = _soup(100, 300, 5)
+    v0, f0 = v.clone(), f.clone()
+    meshops.remove_degenerate(v, f)
+    assert torch.equal(v, v0) and torch.equal(f, f0)
+    ev, ef = meshops.remove_floaters(torch.zeros(0, 3, device="cuda"), torch.zeros(0, 3, dtype=torch.int32, device="cuda"))
+    assert ev.shape == (0, 3) and ef.shape == (0, 3)
+    with pytest.raises(ValueError):
+        meshops.remove_degenerate(v.cpu(), f.cpu())       # no CPU path
+
+
+def test_postprocessor_classes_keep_the_mesh_on_the_gpu():
+    from hy3dgen.shapegen import DegenerateFaceRemover, FaceReducer, FloaterRemover
+    from oracle import mesh_clean
+    from r3g.mesh import Mesh
+    v, f = _mc_mesh(65, 4)
+    m = Mesh.from_device(v, f)
+    for c in (FloaterRemover(), DegenerateFaceRemover(), FaceReducer()):
+        m = c(m)
+    assert m._v is None and m.n_faces <= 40000            # nothing was downloaded on the way
+    w = mesh_clean.remove_floaters(v.cpu().numpy(), f.cpu().numpy())
+    w = mesh_clean.remove_degenerate(*w)
+    w = mesh_clean.reduce_faces(*w, 40000)
+    assert np.array_equal(m.faces, w[1]) and np.array_equal(m.vertices.astype(np.float32), w[0])
+    host = Mesh(v.cpu().numpy(), f.cpu().numpy())         # host-born mesh: uploaded, same answer
+    h = FaceReducer()(host, max_facenum=2000)
+    w2 = mesh_clean.reduce_faces(v.cpu().numpy(), f.cpu().numpy(), 2000)
+    assert np.array_equal(h.faces, w2[1])
+    data = h.export(file_type="glb")
+    assert data[:4] == b"glTF"
