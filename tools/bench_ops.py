@@ -25,6 +25,10 @@ def timeit(fn, iters=10, warm=2):
     return a.elapsed_time(b) / iters
 
 
+SWEEP = [tuple(int(x) for x in item.split(':')) for item in
+         os.environ.get('R3G_BENCH_SWEEP', '4:0,8:0,9:4').split(',')]   # waves:raster_group pairs
+
+
 def main():
     ffi.context(0)
     L = ffi.lib()
@@ -36,7 +40,7 @@ def main():
         w = torch.randn(N, K, device="cuda").to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
-        for waves, raster in ((4, 0), (8, 0), (9, 4), (10, 0), (10, 4)):
+        for waves, raster in SWEEP:
             ffi.check(L.r3g_set_option(b"gemm_waves", waves))
             ffi.check(L.r3g_set_option(b"gemm_raster", raster))
             ms = timeit(lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
