@@ -159,10 +159,21 @@ __global__ void uf_flatten_kernel(int* __restrict__ parent, int64_t n) {
     }
 }
 
+// Faces per component.  Most faces of a wave belong to the same (large) component, and same-address atomics
+// serialise in L2: lanes with equal roots are merged first (one atomic per distinct root per wave).
 __global__ void comp_count_kernel(const int32_t* __restrict__ faces, int64_t nf, const int* __restrict__ root,
                                   unsigned* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nf) atomicAdd(&cnt[root[faces[3 * i]]], 1u);
+    const int lane = threadIdx.x & 63;
+    int r = i < nf ? root[faces[3 * i]] : -1;
+    unsigned long long todo = __ballot(r >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lr = __shfl(r, leader, 64);
+        const unsigned long long same = __ballot(r == lr) & todo;
+        if (lane == leader) atomicAdd(&cnt[lr], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ void max_u32_kernel(const unsigned* __restrict__ v, int64_t n, unsigned* __restrict__ out) {
@@ -173,7 +184,7 @@ __global__ void max_u32_kernel(const unsigned* __restrict__ v, int64_t n, unsign
         const unsigned o = __shfl_xor(m, d, 64);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m > *(volatile unsigned*)out) atomicMax(out, m);   // skip atomics that cannot win
 }
 
 // keep[f] = faces-of-component >= max(1, ceil(min_ratio * largest))
@@ -257,9 +268,9 @@ __global__ void bbox_kernel(const float* __restrict__ verts, int64_t nv, unsigne
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[a], lo[a]);
-            atomicMax(&bbox[3 + a], hi[a]);
+        for (int a = 0; a < 3; ++a) {   // same-address atomics serialise: only the ones that still improve the box
+            if (lo[a] < *(volatile unsigned*)&bbox[a]) atomicMin(&bbox[a], lo[a]);
+            if (hi[a] > *(volatile unsigned*)&bbox[3 + a]) atomicMax(&bbox[3 + a], hi[a]);
         }
     }
 }

@@ -105,6 +105,43 @@ def test_random_volumes_vs_oracle(gmc):
         assert bits_equal(v, ov), shape
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 257), (5, 19, 257), (4, 9, 513), (3, 40, 769)])
+def test_row_kernel_shapes_vs_oracle(gmc, shape):
+    """Row length % 256 == 0 takes the row-marching classify kernel (4 cells per lane, float-domain sign test,
+    LDS lane packing): dense noise (every cell active), exact ties with the level, levels that are / are not
+    float32 values, infinities -- all against the oracle, bit for bit."""
+    from oracle import mc as omc
+    rng = np.random.default_rng(hash(shape) % 1000)
+    noise = rng.standard_normal(shape).astype(np.float32)
+    ties = np.round(noise * 2).astype(np.float32) / 2
+    smooth = noise.copy()
+    for _ in range(3):
+        for ax in range(3):
+            smooth = (np.roll(smooth, 1, ax) + 2 * smooth + np.roll(smooth, -1, ax)) / 4
+    smooth = smooth.astype(np.float32)
+    spiky = smooth.copy()
+    spiky[0, 0, 5] = np.inf
+    spiky[-1, -1, -7] = -np.inf
+    cases = [(noise, 0.0), (noise, 0.1), (ties, 0.5), (ties, 0.25), (smooth, 0.0), (smooth, float(np.float32(0.01))),
+             (smooth, 0.01), (smooth, 1e-300), (spiky, 0.0)]
+    for vol, level in cases:
+        ov, of = omc.marching_cubes(vol, level)
+        v, f = gmc(vol, level)
+        assert np.array_equal(f, of), (shape, level)
+        assert bits_equal(v, ov), (shape, level)
+
+
+def test_row_kernel_range_errors(gmc):
+    vol = np.zeros((3, 3, 257), np.float32)
+    with pytest.raises(RuntimeError):          # level inside [min, max] but no crossing: "No surface found"
+        gmc(vol, 0.0)
+    with pytest.raises(ValueError):
+        gmc(vol, 1.0)
+    vol[1, 1, 100] = np.nan                     # NaN disables the range check, as numpy's comparisons do
+    with pytest.raises(RuntimeError):
+        gmc(vol, 1.0)
+
+
 def test_full_size_grid_vs_oracle(gmc):
     """257^3 (the reference's octree_resolution_hy=256, src/config.yaml:168): smooth random field with
     genuinely ambiguous cells, compared in full with the oracle."""
