@@ -94,9 +94,10 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 
 // Epilogue shared by all GEMM kernels.  acc[j][i]: wave-local sub-tile (n group j of 16 columns, m group i of 16 rows);
 // lane holds row m = m0 + wr*WROWS + i*16 + (lane&15), columns n0 + wc*64 + j*16 + (lane>>4)*4 + {0..3}.
+// lds_wave: wave-private LDS scratch of WROWS x 128 bytes (free once the k-loop's last barrier has passed), or null.
 template <int EPI, int MI, bool SMALLREG>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
-                                              int wc, int lane) {
+                                              int wc, int lane, char* lds_wave = nullptr) {
     constexpr int WROWS = MI * 16;
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
@@ -190,6 +191,58 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     const int mrow = m0 + wr * WROWS + (lane & 15);
     const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
     const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
+    if constexpr (EPI == EPI_RESID_F32) {
+        float* X = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.strideC;
+        const bool wide = lds_wave != nullptr && (p.ldc & 3) == 0 && (p.strideC & 3) == 0 &&
+                          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+        if (wide) {
+            // Read-modify-write through a wave-private LDS transpose, 32 columns (two 16-column groups) per pass: the
+            // global accesses become 8 rows x 128 contiguous bytes per instruction instead of 16 rows x 64 bytes.
+            const int cc = lane & 7;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * jp + jj;
+                    const int nb = ncol + j * 16;
+                    const int nbc = nb < p.N ? nb : p.N - 4;
+                    f32x4 bj = (f32x4){0.f, 0.f, 0.f, 0.f}, gj = (f32x4){1.f, 1.f, 1.f, 1.f};
+                    if (p.bias) bj = *reinterpret_cast<const f32x4*>(p.bias + nbc);
+                    if (gate) gj = *reinterpret_cast<const f32x4*>(gate + nbc);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int r = i * 16 + (lane & 15);
+                        const int chunk = (jj * 4 + (lane >> 4)) ^ (r & 7);
+                        *reinterpret_cast<f32x4*>(lds_wave + r * 128 + chunk * 16) = gj * (acc[j][i] + bj);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int n = n0 + wc * 64 + jp * 32 + cc * 4;
+                const int nc = n < p.N ? n : p.N - 4;
+#pragma unroll
+                for (int t0 = 0; t0 < WROWS / 8; t0 += 4) {
+                    f32x4 old[4];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int m = m0 + wr * WROWS + (t0 + tt) * 8 + (lane >> 3);
+                        const int mc = m < p.M ? m : p.M - 1;
+                        old[tt] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int rr = (t0 + tt) * 8 + (lane >> 3);
+                        const int m = m0 + wr * WROWS + rr;
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                        if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = old[tt] + d;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+    }
     f32x4 biasv[4], gatev[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -227,6 +280,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 }
         }
     } else {
+        // bf16 outputs go through a wave-private LDS transpose when the layout allows 16-byte stores: a store
+        // instruction then writes 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 32 bytes
+        const bool wide = EPI != EPI_F32 && lds_wave != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
+                          (p.strideC & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -240,7 +297,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                 }
-                if (n < p.N && m < p.M) {
+                if (EPI != EPI_F32 && wide) {
+                    uint2 pk;
+                    pk.x = pack_bf16(v[0], v[1]);
+                    pk.y = pack_bf16(v[2], v[3]);
+                    const int r = i * 16 + (lane & 15), q = lane >> 4;
+                    const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
+                    *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
+                } else if (n < p.N && m < p.M) {
                     const int64_t off = cbase + (int64_t)m * p.ldc + n;
                     if (EPI == EPI_F32) {
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
@@ -252,6 +316,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     }
                 }
             }
+        if (EPI != EPI_F32 && wide) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
+            const int cc = lane & 7, n = n0 + wc * 64 + cc * 8;
+#pragma unroll
+            for (int t = 0; t < WROWS / 8; ++t) {
+                const int rr = t * 8 + (lane >> 3);
+                const int m = m0 + wr * WROWS + rr;
+                const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
+            }
+        }
     }
 }
 
@@ -351,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane);
+    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane, smem + wid * (WROWS * 128));
 }
 
 // ------------------------------------------------------------------------------------------------------------
