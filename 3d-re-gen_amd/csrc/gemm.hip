@@ -149,6 +149,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     v[j] = (v[j] - mean) * r * w + b;
                 }
             }
+            if (lds_wave != nullptr) {
+                // stage the normalised tile in the wave's LDS scratch: Q / K as [token][64 dims] (16-byte chunks
+                // swizzled by the token), V as [dim][token] (chunks of 8 tokens swizzled by the dim group)
+                const int r = i * 16 + (lane & 15), q = lane >> 4;
+                if (type < 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint2 pk;
+                        pk.x = pack_bf16(v[j][0], v[j][1]);
+                        pk.y = pack_bf16(v[j][2], v[j][3]);
+                        const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
+                        *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int d = j * 16 + q * 4 + c;
+                            const int chunk = (r >> 3) ^ ((d >> 2) & (WROWS / 8 - 1));
+                            *reinterpret_cast<uint16_t*>(lds_wave + d * (WROWS * 2) + chunk * 16 + (r & 7) * 2) =
+                                (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
+                        }
+                }
+                continue;
+            }
             if (m >= p.M) continue;
             int64_t drow = (int64_t)e.dst_row0 + m;
             int ob = batch;
@@ -181,6 +207,70 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
+            }
+        }
+        if (lds_wave != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // destination of tile row `rr` (token m): attention batch and row, or -1 when the row is dropped
+            auto map_row = [&](int m, int& ob, int64_t& drow) {
+                ob = batch;
+                drow = (int64_t)e.dst_row0 + m;
+                if (m >= p.M) return false;
+                if (e.nseg == 0) return true;
+                bool hit = false;
+#pragma unroll
+                for (int sgi = 0; sgi < 3; ++sgi)
+                    if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
+                        hit = true;
+                        ob = e.seg_batch[sgi];
+                        drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
+                    }
+                return hit;
+            };
+            const int mw = m0 + wr * WROWS;
+            if (type < 2) {
+                // 8 tokens x 128 contiguous bytes per store instruction (a token's 64 dims are one cache line)
+                const int cc = lane & 7;
+#pragma unroll
+                for (int t = 0; t < WROWS / 8; ++t) {
+                    const int rr = t * 8 + (lane >> 3);
+                    int ob;
+                    int64_t drow;
+                    if (!map_row(mw + rr, ob, drow)) continue;
+                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
+                                                : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
+                    *reinterpret_cast<uint4*>(base + cc * 8) = dv;
+                }
+            } else {
+                // V^T[dim][token]: a lane takes 8 consecutive tokens of one dim (16 bytes) when they stay together in
+                // the destination, otherwise token by token (segment boundaries, the ragged end of the rows)
+                constexpr int CPR = WROWS / 8;   // 16-byte chunks per dim row
+#pragma unroll
+                for (int t = 0; t < 64 / (64 / CPR); ++t) {
+                    const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
+                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + d * (WROWS * 2) +
+                                                                     ((ck ^ ((d >> 2) & (CPR - 1))) << 4));
+                    const int mfirst = mw + ck * 8;
+                    int ob0, ob7;
+                    int64_t dr0, dr7;
+                    const bool ok0 = map_row(mfirst, ob0, dr0), ok7 = map_row(mfirst + 7, ob7, dr7);
+                    const int64_t lk = e.Lk_pad;
+                    if (ok0 && ok7 && ob0 == ob7 && dr7 == dr0 + 7 && ((dr0 | lk) & 7) == 0) {
+                        uint16_t* dst = e.Vt + (((int64_t)ob0 * e.heads + head) * 64 + d) * lk + dr0;
+                        *reinterpret_cast<uint4*>(dst) = dv;
+                    } else {
+                        const uint16_t* h = reinterpret_cast<const uint16_t*>(&dv);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            int ob;
+                            int64_t dr;
+                            if (map_row(mfirst + k, ob, dr))
+                                e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + dr] = h[k];
+                        }
+                    }
+                }
             }
         }
         return;
@@ -428,7 +518,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane, smem + wid * (WROWS * 128));
+    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane,
+                                       p.wide_epilogue ? smem + wid * (WROWS * 128) : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -576,6 +667,7 @@ hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
 
 static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
+bool g_gemm_wide_epilogue = true;
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
@@ -600,6 +692,7 @@ hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
 static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
+void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_config(int waves, int stages) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
@@ -608,7 +701,8 @@ void gemm_set_config(int waves, int stages) {
 hipError_t gemm_launch(const GemmArgs& p_in, int batch, hipStream_t s) {
     GemmArgs p = p_in;
     p.batch = batch;
-    p.raster_group = g_gemm_raster;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
+    p.raster_group = g_gemm_raster;
+    p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
     if (p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);

@@ -52,6 +52,7 @@ struct GemmArgs {
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
     int batch;          // filled in by gemm_launch
+    int wide_epilogue;  // 1: stores go through the wave-private LDS transpose (row-contiguous 16-byte accesses)
     int raster_group;   // tile columns per rasterisation group (0 = row-major), filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
 };
@@ -61,7 +62,8 @@ void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-sta
 void attn_set_glds(bool on);
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
 void gemm_set_config(int waves, int stages);
-void gemm_set_raster(int group);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
+void gemm_set_raster(int group);
+void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
 struct AttnArgs {
