@@ -425,8 +425,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 // NW = 4: waves 2(m) x 2(n), 64x64 per wave.  NW = 8: waves 4(m) x 2(n), 32x64 per wave (a wave always owns 64
 // whole columns = one attention head for the EPI_QKV epilogue).  NS = LDS stages (2: wait for everything each k-tile;
 // 3: LDS-DMA of tile t+2 stays in flight across the barrier -- counted vmcnt + raw s_barrier).
+// Two problems can share one launch (pb.M > 0): the tiles of pb follow those of pa in the grid.  The two streams of a
+// DiT double block run the same layer shapes on different weights; the short one (1371 context rows = 88 tiles of
+// 128x128) would leave two thirds of the CUs idle on its own.
 template <int EPI, bool GLDS, int NW, int BIG>
-__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs pa, GemmArgs pb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // BIG = 1: 256x256 tile (16 waves of 64x64, or 8 waves of 128x64); BIG = 0: 128x128 (4 waves 64x64 / 8 waves 32x64)
     //       BIG = 2: 256x128 tile (8 waves of 64x64): 1/3 less staging traffic than 128x128, finer grid than 256x256
@@ -441,7 +444,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs p) {
     // XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
+    const bool second = wg_all >= tiles_a;                 // wave-uniform
+    // the selected problem is read straight from the kernarg segment (scalar loads at a uniform offset); selecting
+    // between the two by-value structs would make the compiler copy both to scratch
+    typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kSecond = (sizeof(GemmArgs) + alignof(GemmArgs) - 1) / alignof(GemmArgs) * alignof(GemmArgs);
+    const GemmArgs& p = *(const GemmArgs*)(const GemmArgs __attribute__((address_space(4)))*)(ka + (second ? kSecond : 0));
+    (void)pb;
+    const int wg = second ? wg_all - tiles_a : wg_all;
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -643,9 +656,10 @@ hipError_t launch_deep(const GemmArgs& p, int batch, hipStream_t s) {
 }
 
 template <int EPI, int NW, int BIG>
-hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
+hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStream_t s) {
     constexpr int BM = BIG ? 256 : 128, BN = BIG == 1 ? 256 : 128;
-    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
+    int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.batch;
+    if (p2.M > 0) tiles += ((p2.N + BN - 1) / BN) * ((p2.M + BM - 1) / BM) * p2.batch;
     const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
     auto kt = gemm_kernel<EPI, true, NW, BIG>;
     auto kf = gemm_kernel<EPI, false, NW, BIG>;
@@ -658,9 +672,9 @@ hipError_t launch_cfg(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
         }
     }
     if (glds) {
-        hipLaunchKernelGGL(kt, dim3(tiles), dim3(NW * 64), lds, s, p);
+        hipLaunchKernelGGL(kt, dim3(tiles), dim3(NW * 64), lds, s, p, p2);
     } else {
-        hipLaunchKernelGGL(kf, dim3(tiles), dim3(NW * 64), lds, s, p);
+        hipLaunchKernelGGL(kf, dim3(tiles), dim3(NW * 64), lds, s, p, p2);
     }
     return hipGetLastError();
 }
@@ -670,21 +684,22 @@ int g_gemm_raster = -1;
 bool g_gemm_wide_epilogue = true;
 
 template <int EPI>
-hipError_t launch_epi(const GemmArgs& p, int batch, bool glds, hipStream_t s) {
+hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStream_t s) {
     int waves = g_gemm_waves;
+    const int batch = p.batch;
     if (waves == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
         // flop) win for long K or very many tiles; 128x128 with 8 waves wins slightly for N <= 1024, 4 waves otherwise
         const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        if (EPI != EPI_QKV && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
+        if (EPI != EPI_QKV && p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
         else waves = p.N <= 1024 ? 8 : 4;
     }
-    if (waves == 32 && p.K % 32 == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
-    if (waves == 16) return launch_cfg<EPI, 16, 1>(p, batch, glds, s);
-    if (waves == 9) return launch_cfg<EPI, 8, 1>(p, batch, glds, s);   // 256x256 tile, 8 waves of 128x64
-    if (waves == 10) return launch_cfg<EPI, 8, 2>(p, batch, glds, s);  // 256x128 tile, 8 waves of 64x64
-    if (waves == 8) return launch_cfg<EPI, 8, 0>(p, batch, glds, s);
-    return launch_cfg<EPI, 4, 0>(p, batch, glds, s);
+    if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
+    if (waves == 16) return launch_cfg<EPI, 16, 1>(p, p2, glds, s);
+    if (waves == 9) return launch_cfg<EPI, 8, 1>(p, p2, glds, s);   // 256x256 tile, 8 waves of 128x64
+    if (waves == 10) return launch_cfg<EPI, 8, 2>(p, p2, glds, s);  // 256x128 tile, 8 waves of 64x64
+    if (waves == 8) return launch_cfg<EPI, 8, 0>(p, p2, glds, s);
+    return launch_cfg<EPI, 4, 0>(p, p2, glds, s);
 }
 
 }  // namespace
@@ -698,25 +713,40 @@ void gemm_set_config(int waves, int stages) {
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 
-hipError_t gemm_launch(const GemmArgs& p_in, int batch, hipStream_t s) {
-    GemmArgs p = p_in;
+static bool gemm_args_ok(const GemmArgs& p) {
+    return !(p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7) || (p.epi == EPI_QKV && p.N % 64));
+}
+
+// One launch for one problem (p2 == nullptr) or for two problems with the same epilogue (and hence kernel).
+hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, int batch2, hipStream_t s) {
+    GemmArgs p = p_in, p2{};
     p.batch = batch;
-    p.raster_group = g_gemm_raster;
-    p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
-    if (p.M <= 0 || p.N <= 0 || batch <= 0) return hipSuccess;
-    if (p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
-    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch, s);
+    p.raster_group = g_gemm_raster;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
+    p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;
+    if (p2_in && p2_in->M > 0 && p2_in->N > 0 && batch2 > 0) {
+        p2 = *p2_in;
+        p2.batch = batch2;
+        p2.raster_group = p.raster_group;
+        p2.wide_epilogue = p.wide_epilogue;
+        if (p2.epi != p.epi || !gemm_args_ok(p2)) return hipErrorInvalidValue;
+    }
+    if (p.M <= 0 || p.N <= 0 || batch <= 0) {
+        if (p2.M > 0) return gemm_launch2(*p2_in, batch2, nullptr, 0, s);
+        return hipSuccess;
+    }
+    if (!gemm_args_ok(p)) return hipErrorInvalidValue;
+    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s);
     switch (p.epi) {
-        case EPI_BF16: return launch_epi<EPI_BF16>(p, batch, g_gemm_glds, s);
-        case EPI_BF16_GELU_TANH: return launch_epi<EPI_BF16_GELU_TANH>(p, batch, g_gemm_glds, s);
-        case EPI_BF16_GELU_ERF: return launch_epi<EPI_BF16_GELU_ERF>(p, batch, g_gemm_glds, s);
-        case EPI_RESID_F32: return launch_epi<EPI_RESID_F32>(p, batch, g_gemm_glds, s);
-        case EPI_F32: return launch_epi<EPI_F32>(p, batch, g_gemm_glds, s);
-        case EPI_QKV:
-            if (p.N % 64) return hipErrorInvalidValue;
-            return launch_epi<EPI_QKV>(p, batch, g_gemm_glds, s);
+        case EPI_BF16: return launch_epi<EPI_BF16>(p, p2, g_gemm_glds, s);
+        case EPI_BF16_GELU_TANH: return launch_epi<EPI_BF16_GELU_TANH>(p, p2, g_gemm_glds, s);
+        case EPI_BF16_GELU_ERF: return launch_epi<EPI_BF16_GELU_ERF>(p, p2, g_gemm_glds, s);
+        case EPI_RESID_F32: return launch_epi<EPI_RESID_F32>(p, p2, g_gemm_glds, s);
+        case EPI_F32: return launch_epi<EPI_F32>(p, p2, g_gemm_glds, s);
+        case EPI_QKV: return launch_epi<EPI_QKV>(p, p2, g_gemm_glds, s);
         default: return hipErrorInvalidValue;
     }
 }
+
+hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) { return gemm_launch2(p, batch, nullptr, 0, s); }
 
 }  // namespace r3g

@@ -58,6 +58,8 @@ struct GemmArgs {
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
+// two problems with the same epilogue in one launch (the second one's tiles follow the first one's); p2 may be null
+hipError_t gemm_launch2(const GemmArgs& p, int batch, const GemmArgs* p2, int batch2, hipStream_t s);
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one

@@ -45,6 +45,7 @@ struct Lin {
 
 static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
@@ -131,9 +132,8 @@ static int get_vec(const Model& m, const std::string& name, int64_t n, const flo
 }
 
 // ---- thin launch helpers -----------------------------------------------------------------------------
-static int gemm(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, int n_off, int N, void* C, int64_t ldc,
-                int64_t strideC, int M, int K, int epi, const float* gate, int64_t strideGate, int batch, hipStream_t s) {
-    if (K > l.K) return fail(R3G_ERR_INVALID, "gemm: K=%d exceeds weight K=%d", K, l.K);
+static GemmArgs gemm_args(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, int n_off, int N, void* C,
+                          int64_t ldc, int64_t strideC, int M, int K, int epi, const float* gate, int64_t strideGate) {
     GemmArgs p{};
     p.A = A; p.lda = lda; p.strideA = strideA;
     p.W = l.w + (int64_t)n_off * l.ldw; p.ldw = l.ldw;
@@ -141,6 +141,26 @@ static int gemm(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, i
     p.C = C; p.ldc = ldc; p.strideC = strideC;
     p.gate = gate; p.strideGate = strideGate;
     p.M = M; p.N = N; p.K = K; p.epi = epi;
+    return p;
+}
+
+// the same layer of the two streams of a double block: one launch (or two, with group_streams = 0)
+static int gemm_pair(const GemmArgs& a, int batch_a, const GemmArgs& b, int batch_b, hipStream_t s) {
+    hipError_t e;
+    if (g_group_streams) {
+        e = gemm_launch2(a, batch_a, &b, batch_b, s);
+    } else {
+        e = gemm_launch(a, batch_a, s);
+        if (e == hipSuccess) e = gemm_launch(b, batch_b, s);
+    }
+    if (e != hipSuccess) return hip_fail(e, "gemm_launch(pair)");
+    return R3G_OK;
+}
+
+static int gemm(const uint16_t* A, int64_t lda, int64_t strideA, const Lin& l, int n_off, int N, void* C, int64_t ldc,
+                int64_t strideC, int M, int K, int epi, const float* gate, int64_t strideGate, int batch, hipStream_t s) {
+    if (K > l.K) return fail(R3G_ERR_INVALID, "gemm: K=%d exceeds weight K=%d", K, l.K);
+    const GemmArgs p = gemm_args(A, lda, strideA, l, n_off, N, C, ldc, strideC, M, K, epi, gate, strideGate);
     hipError_t e = gemm_launch(p, batch, s);
     if (e != hipSuccess) return hip_fail(e, "gemm_launch");
     return R3G_OK;
@@ -401,8 +421,8 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         R3G_RC(get_vec(m, kn, 64, &q->kw));
         return R3G_OK;
     };
-    auto launch_qkv = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, int batch, const QkvSplitArgs& q, int nseg,
-                          const int (*seg)[4]) -> int {
+    auto qkv_gemm_args = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, const QkvSplitArgs& q, int nseg,
+                             const int (*seg)[4]) {
         GemmArgs p{};
         p.A = A; p.lda = H; p.strideA = strideA; p.W = lin.w; p.ldw = lin.ldw; p.bias = lin.b;
         p.M = M; p.N = 3 * H; p.K = H; p.epi = EPI_QKV;
@@ -412,7 +432,11 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         for (int i = 0; i < nseg; ++i) {
             p.qkv.seg_m0[i] = seg[i][0]; p.qkv.seg_m1[i] = seg[i][1]; p.qkv.seg_batch[i] = seg[i][2]; p.qkv.seg_dst[i] = seg[i][3];
         }
-        hipError_t e = gemm_launch(p, batch, s);
+        return p;
+    };
+    auto launch_qkv = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, int batch, const QkvSplitArgs& q, int nseg,
+                          const int (*seg)[4]) -> int {
+        hipError_t e = gemm_launch(qkv_gemm_args(A, strideA, lin, M, q, nseg, seg), batch, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv dedup)");
         return R3G_OK;
     };
@@ -421,39 +445,40 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         const std::string bi = fmt("model.double_blocks.%d.img", i), bt = fmt("model.double_blocks.%d.txt", i);
         const float* mi = m.mod_all + m.mod_off[2 * i];
         const float* mt = m.mod_all + m.mod_off[2 * i + 1];
-        QkvSplitArgs q;
-        // img stream: two latent blocks (batch 2, stride R1 rows)
-        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + H, mi, 0, 1e-6f, s));
-        R3G_RC(get_lin(m, bi + "_attn.qkv", c.dit_qkv_bias != 0, &l));
-        R3G_RC(qkv_args(bi + "_attn.norm.query_norm.scale", bi + "_attn.norm.key_norm.scale", &q));
-        R3G_RC(launch_qkv(m.xn, latS, l, Nl, 2, q, 0, nullptr));
-        // txt stream: Lc cond tokens (entry 0) + 1 unconditional token (entry 1)
+        QkvSplitArgs qi, qt;
+        Lin li, lt;
+        // img stream: two latent blocks (batch 2, stride R1 rows); txt stream: Lc cond tokens (entry 0) + 1
+        // unconditional token (entry 1).  Each layer of the two streams is one grouped launch.
         float* xt = m.f32a + (int64_t)Nl * H;
         uint16_t* xnt = m.xn + (int64_t)Nl * H;
+        uint16_t* catt = m.cat + (int64_t)Nl * catld;
+        const int64_t catS = (int64_t)R1 * catld;
+        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + H, mi, 0, 1e-6f, s));
         R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + H, mt, 0, 1e-6f, s));
-        R3G_RC(get_lin(m, bt + "_attn.qkv", c.dit_qkv_bias != 0, &l));
-        R3G_RC(qkv_args(bt + "_attn.norm.query_norm.scale", bt + "_attn.norm.key_norm.scale", &q));
+        R3G_RC(get_lin(m, bi + "_attn.qkv", c.dit_qkv_bias != 0, &li));
+        R3G_RC(get_lin(m, bt + "_attn.qkv", c.dit_qkv_bias != 0, &lt));
+        R3G_RC(qkv_args(bi + "_attn.norm.query_norm.scale", bi + "_attn.norm.key_norm.scale", &qi));
+        R3G_RC(qkv_args(bt + "_attn.norm.query_norm.scale", bt + "_attn.norm.key_norm.scale", &qt));
         const int seg_t[2][4] = {{0, Lc, 0, Nl}, {Lc, Lc + 1, 1, Nl}};
-        R3G_RC(launch_qkv(xnt, 0, l, Ltxt, 1, q, 2, seg_t));
+        R3G_RC(gemm_pair(qkv_gemm_args(m.xn, latS, li, Nl, qi, 0, nullptr), 2, qkv_gemm_args(xnt, 0, lt, Ltxt, qt, 2, seg_t), 1, s));
         hipError_t e = attention_launch(at, s);
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
-        // img: proj + mlp
-        R3G_RC(get_lin(m, bi + "_attn.proj", true, &l));
-        R3G_RC(gemm(m.cat, catld, (int64_t)R1 * catld, l, 0, H, m.f32a, H, latS, Nl, H, EPI_RESID_F32, mi + 2 * H, 0, 2, s));
+        // attention projection
+        R3G_RC(get_lin(m, bi + "_attn.proj", true, &li));
+        R3G_RC(get_lin(m, bt + "_attn.proj", true, &lt));
+        R3G_RC(gemm_pair(gemm_args(m.cat, catld, catS, li, 0, H, m.f32a, H, latS, Nl, H, EPI_RESID_F32, mi + 2 * H, 0), 2,
+                         gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Ltxt, H, EPI_RESID_F32, mt + 2 * H, 0), 1, s));
+        // MLP
         R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + 4 * H, mi + 3 * H, 0, 1e-6f, s));
-        R3G_RC(get_lin(m, bi + "_mlp.0", true, &l));
-        R3G_RC(gemm(m.xn, H, latS, l, 0, mh, m.cat + H, catld, (int64_t)R1 * catld, Nl, H, EPI_BF16_GELU_TANH, nullptr, 0, 2, s));
-        R3G_RC(get_lin(m, bi + "_mlp.2", true, &l));
-        R3G_RC(gemm(m.cat + H, catld, (int64_t)R1 * catld, l, 0, H, m.f32a, H, latS, Nl, mh, EPI_RESID_F32, mi + 5 * H, 0, 2, s));
-        // txt: proj + mlp
-        uint16_t* catt = m.cat + (int64_t)Nl * catld;
-        R3G_RC(get_lin(m, bt + "_attn.proj", true, &l));
-        R3G_RC(gemm(catt, catld, 0, l, 0, H, xt, H, 0, Ltxt, H, EPI_RESID_F32, mt + 2 * H, 0, 1, s));
         R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + 4 * H, mt + 3 * H, 0, 1e-6f, s));
-        R3G_RC(get_lin(m, bt + "_mlp.0", true, &l));
-        R3G_RC(gemm(xnt, H, 0, l, 0, mh, catt + H, catld, 0, Ltxt, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, s));
-        R3G_RC(get_lin(m, bt + "_mlp.2", true, &l));
-        R3G_RC(gemm(catt + H, catld, 0, l, 0, H, xt, H, 0, Ltxt, mh, EPI_RESID_F32, mt + 5 * H, 0, 1, s));
+        R3G_RC(get_lin(m, bi + "_mlp.0", true, &li));
+        R3G_RC(get_lin(m, bt + "_mlp.0", true, &lt));
+        R3G_RC(gemm_pair(gemm_args(m.xn, H, latS, li, 0, mh, m.cat + H, catld, catS, Nl, H, EPI_BF16_GELU_TANH, nullptr, 0), 2,
+                         gemm_args(xnt, H, 0, lt, 0, mh, catt + H, catld, 0, Ltxt, H, EPI_BF16_GELU_TANH, nullptr, 0), 1, s));
+        R3G_RC(get_lin(m, bi + "_mlp.2", true, &li));
+        R3G_RC(get_lin(m, bt + "_mlp.2", true, &lt));
+        R3G_RC(gemm_pair(gemm_args(m.cat + H, catld, catS, li, 0, H, m.f32a, H, latS, Nl, mh, EPI_RESID_F32, mi + 5 * H, 0), 2,
+                         gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Ltxt, mh, EPI_RESID_F32, mt + 5 * H, 0), 1, s));
     }
     const int seg_s[3][4] = {{0, T, 0, 0}, {T, T + 1, 1, Nl}, {R1, R1 + Nl, 1, 0}};
     for (int i = 0; i < c.dit_depth_single; ++i) {
@@ -851,6 +876,7 @@ int r3g_set_option(const char* name, int value) {
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
+    else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);
     else if (!strcmp(name, "gemm_stages")) gemm_set_config(0, value);
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);

@@ -260,3 +260,22 @@ def test_cfg_dedup_full_width(wide):
     out = wide.gpu.flow_sample(lat0.clone(), cond, 2, 5.0)
     ref = wide.oracle.sample(cond, lat0[None].clone(), 2, 5.0)[0]
     assert rel_l2(out, ref) <= 3e-2
+
+
+@pytest.mark.parametrize("which", ["tiny", "wide"])
+def test_grouped_stream_launches_are_bit_identical(which, tiny, wide):
+    """The two streams of a double block share one GEMM launch (gemm_launch2); packing two problems into one grid
+    must not change a single bit with respect to separate launches."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    st = tiny if which == "tiny" else wide
+    x, _, cond = _inputs(st, 21)
+    lat0 = x[0]
+    a = st.gpu.flow_sample(lat0.clone(), cond, 2, 5.0).clone()
+    try:
+        ffi.check(L.r3g_set_option(b"group_streams", 0))
+        b = st.gpu.flow_sample(lat0.clone(), cond, 2, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"group_streams", 1))
+    assert torch.equal(a, b)
