@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             ss += a * a + b * b + c * c + d * d;
         }
     const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
-    const float* sc = p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr;
-    const float* sh = p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr;
+    const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave)
+    const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
+    const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
     uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
@@ -104,8 +105,9 @@ __global__ __launch_bounds__(256) void layernorm_small_kernel(LnArgs p) {
     for (int i = 0; i < 32; ++i)
         if (i < n) { const float a = v[i] - mean; ss += a * a; }
     const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
-    const float* sc = p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr;
-    const float* sh = p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr;
+    const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave)
+    const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
+    const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
     uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
 #pragma unroll
     for (int i = 0; i < 32; ++i)

@@ -691,7 +691,7 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
         // flop) win for long K or very many tiles; 128x128 with 8 waves wins slightly for N <= 1024, 4 waves otherwise
         const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        if (EPI != EPI_QKV && p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
+        if (p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
         else waves = p.N <= 1024 ? 8 : 4;
     }
     if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel

@@ -101,6 +101,10 @@ struct LnArgs {
     int64_t x_batch_stride, y_batch_stride;  // row r lives at batch (r / rows_per_batch), local row r % rows_per_batch
     const float* w; const float* b;     // affine [C] or null
     const float* scale; const float* shift; int64_t mod_stride;  // per-batch [C] or null
+    // rows in [seg2_row0, seg2_row1) use scale2 / shift2 instead (the txt-stream rows of a DiT double block, whose
+    // modulation differs from the img rows around them); seg2_row1 <= seg2_row0: unused
+    int seg2_row0, seg2_row1;
+    const float* scale2; const float* shift2;
     int rows, C, rows_per_batch;
     float eps;
 };

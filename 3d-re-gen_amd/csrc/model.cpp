@@ -441,6 +441,25 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         return R3G_OK;
     };
 
+    // LayerNorm + modulation of both streams: one launch over all rows [0, Rtot) (the txt rows take their own
+    // scale / shift; the pad rows between the blocks are normalised too and never read), or one launch per stream
+    auto ln_streams = [&](const float* sc_i, const float* sh_i, const float* sc_t, const float* sh_t) -> int {
+        float* xt_ = m.f32a + (int64_t)Nl * H;
+        uint16_t* xnt_ = m.xn + (int64_t)Nl * H;
+        if (!g_group_streams) {
+            R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, sc_i, sh_i, 0, 1e-6f, s));
+            return layernorm(xt_, H, 0, xnt_, H, 0, Ltxt, 1, H, nullptr, nullptr, sc_t, sh_t, 0, 1e-6f, s);
+        }
+        LnArgs p{};
+        p.x = m.f32a; p.ldx = H; p.x_batch_stride = 0;
+        p.y = m.xn; p.ldy = H; p.y_batch_stride = 0;
+        p.scale = sc_i; p.shift = sh_i; p.mod_stride = 0;
+        p.seg2_row0 = Nl; p.seg2_row1 = Nl + Ltxt; p.scale2 = sc_t; p.shift2 = sh_t;
+        p.rows = Rtot; p.C = H; p.rows_per_batch = Rtot; p.eps = 1e-6f;
+        hipError_t e = layernorm_launch(p, s);
+        if (e != hipSuccess) return hip_fail(e, "layernorm_launch(streams)");
+        return R3G_OK;
+    };
     for (int i = 0; i < c.dit_depth_double; ++i) {
         const std::string bi = fmt("model.double_blocks.%d.img", i), bt = fmt("model.double_blocks.%d.txt", i);
         const float* mi = m.mod_all + m.mod_off[2 * i];
@@ -453,8 +472,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         uint16_t* xnt = m.xn + (int64_t)Nl * H;
         uint16_t* catt = m.cat + (int64_t)Nl * catld;
         const int64_t catS = (int64_t)R1 * catld;
-        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + H, mi, 0, 1e-6f, s));
-        R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + H, mt, 0, 1e-6f, s));
+        R3G_RC(ln_streams(mi + H, mi, mt + H, mt));
         R3G_RC(get_lin(m, bi + "_attn.qkv", c.dit_qkv_bias != 0, &li));
         R3G_RC(get_lin(m, bt + "_attn.qkv", c.dit_qkv_bias != 0, &lt));
         R3G_RC(qkv_args(bi + "_attn.norm.query_norm.scale", bi + "_attn.norm.key_norm.scale", &qi));
@@ -469,8 +487,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         R3G_RC(gemm_pair(gemm_args(m.cat, catld, catS, li, 0, H, m.f32a, H, latS, Nl, H, EPI_RESID_F32, mi + 2 * H, 0), 2,
                          gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Ltxt, H, EPI_RESID_F32, mt + 2 * H, 0), 1, s));
         // MLP
-        R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, mi + 4 * H, mi + 3 * H, 0, 1e-6f, s));
-        R3G_RC(layernorm(xt, H, 0, xnt, H, 0, Ltxt, 1, H, nullptr, nullptr, mt + 4 * H, mt + 3 * H, 0, 1e-6f, s));
+        R3G_RC(ln_streams(mi + 4 * H, mi + 3 * H, mt + 4 * H, mt + 3 * H));
         R3G_RC(get_lin(m, bi + "_mlp.0", true, &li));
         R3G_RC(get_lin(m, bt + "_mlp.0", true, &lt));
         R3G_RC(gemm_pair(gemm_args(m.xn, H, latS, li, 0, mh, m.cat + H, catld, catS, Nl, H, EPI_BF16_GELU_TANH, nullptr, 0), 2,
