@@ -45,6 +45,7 @@ struct Lin {
 
 static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+static bool g_overlap_mlp = true;     // single blocks: MLP-in GEMM on a second stream beside the attention kernel
 static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
@@ -78,6 +79,9 @@ struct Model {
     int n_mod_jobs = 0;
     float* mod_all = nullptr;           // [job][B][N]
     std::vector<int64_t> mod_off;       // per job offset into mod_all
+    // second stream: the MLP half of a single block's linear1 runs beside the attention kernel (see dit_forward_cfg_dedup)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     const Tensor* find(const std::string& name) const {
@@ -498,17 +502,39 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
                          gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Ltxt, mh, EPI_RESID_F32, mt + 5 * H, 0), 1, s));
     }
     const int seg_s[3][4] = {{0, T, 0, 0}, {T, T + 1, 1, Nl}, {R1, R1 + Nl, 1, 0}};
+    // Single blocks: linear1 = [qkv | mlp-in].  The attention grid (960 workgroups of unequal length on 768 slots)
+    // leaves a fifth of the machine idle in its second dispatch round; the MLP half of linear1 does not depend on the
+    // attention, so it is issued on a second stream (fork after the LayerNorm, join before linear2) and fills those
+    // slots.  Same kernels, same operands: the result does not change.
+    const bool overlap = g_overlap_mlp && c.dit_depth_single > 0;
+    if (overlap && !m.aux) {
+        R3G_TRY(hipStreamCreateWithFlags(&m.aux, hipStreamNonBlocking));
+        R3G_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
+        R3G_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
+    }
     for (int i = 0; i < c.dit_depth_single; ++i) {
         const std::string blk = fmt("model.single_blocks.%d", i);
         const float* mm = m.mod_all + m.mod_off[2 * c.dit_depth_double + i];
         R3G_RC(layernorm(m.f32a, H, 0, m.xn, H, 0, Rtot, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s));
         R3G_RC(get_lin(m, blk + ".linear1", true, &l));
-        R3G_RC(gemm(m.xn, H, 0, l, 3 * H, mh, m.cat + H, catld, 0, Rtot, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, s));
         QkvSplitArgs q;
         R3G_RC(qkv_args(blk + ".norm.query_norm.scale", blk + ".norm.key_norm.scale", &q));
-        R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+        hipStream_t sm = s;
+        if (overlap) {   // fork after the QKV projection: the MLP-in GEMM starts together with the attention kernel
+            R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+            R3G_TRY(hipEventRecord(m.ev_fork, s));
+            R3G_TRY(hipStreamWaitEvent(m.aux, m.ev_fork, 0));
+            sm = m.aux;
+        }
+        R3G_RC(gemm(m.xn, H, 0, l, 3 * H, mh, m.cat + H, catld, 0, Rtot, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, sm));
+        if (overlap) {
+            R3G_TRY(hipEventRecord(m.ev_join, m.aux));
+        } else {
+            R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+        }
         hipError_t e = attention_launch(at, s);
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
+        if (overlap) R3G_TRY(hipStreamWaitEvent(s, m.ev_join, 0));
         R3G_RC(get_lin(m, blk + ".linear2", true, &l));
         R3G_RC(gemm(m.cat, catld, 0, l, 0, H, m.f32a, H, 0, Rtot, H + mh, EPI_RESID_F32, mm + 2 * H, 0, 1, s));
     }
@@ -693,6 +719,9 @@ static void model_free(Model* m) {
     if (m->arena) (void)hipFree(m->arena);
     if (m->mod_jobs) (void)hipFree(m->mod_jobs);
     if (m->mod_all) (void)hipFree(m->mod_all);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->aux) (void)hipStreamDestroy(m->aux);
     delete m;
 }
 
@@ -894,6 +923,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
+    else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);
     else if (!strcmp(name, "gemm_stages")) gemm_set_config(0, value);
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);
