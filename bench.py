@@ -41,7 +41,7 @@ PEAK_HBM_GBPS = 8000.0
 # HBM-side traffic of the GEMM family per launch, from rocprofv3 PMC passes (profiles/r01_pmc_traffic.md): FETCH_SIZE and
 # WRITE_SIZE collected in separate passes, FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16-byte
 # loads, MI355X_MICROARCH.md "HBM"), per-variant averages weighted by the launch counts of one 50-step object.
-GEMM_TRAFFIC_BYTES_PER_LAUNCH = 2.79e8
+GEMM_TRAFFIC_BYTES_PER_LAUNCH = 3.38e8
 FAMILIES = ["gemm", "attention", "layernorm", "qkv_split", "gemv", "elementwise", "mc_classify", "mc_other", "mesh"]
 
 
@@ -211,9 +211,14 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         L = ffi.lib()
+        # one further object with every launch bracketed by HIP events on its stream.  The second-stream overlap of
+        # the timed region (a GEMM beside the attention kernel) is switched off for this object so that a launch
+        # duration is the kernel's own time, not the time it shared the GPU with another kernel.
+        ffi.check(L.r3g_set_option(b"overlap_mlp", 0))
         ffi.check(L.r3g_prof_enable(1))
         one(crops[a.warmup + a.steps])
         torch.cuda.synchronize()
+        ffi.check(L.r3g_set_option(b"overlap_mlp", 1))
         n = len(FAMILIES)
         cnt, ms, work = (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
         ffi.check(L.r3g_prof_read(cnt, ms, work, n))
@@ -226,6 +231,7 @@ def main():
                            "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if dom == "gemm" else None,
                            "algorithmic_bytes_per_launch": None, "launches": fam[dom]["launches"],
                            "avg_launch_us": 1000.0 * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
+                           "note": "per-launch HIP events on one extra object with overlap_mlp=0 (kernels run alone)",
                            "families_ms_per_object": {k: round(v["ms"], 3) for k, v in fam.items()},
                            "attention_tflops": (fam["attention"]["work"] / (fam["attention"]["ms"] * 1e-3) / 1e12
                                                 if fam["attention"]["ms"] > 0 else 0.0),
