@@ -77,6 +77,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libr3g.so not built: run `python 3d-re-gen_amd/build.py` "
                               "(or __graft_entry__.build()); there is no fallback path")
+        # PyTorch ships its own HIP runtime: it has to be in the process before libr3g.so is, so that both resolve
+        # to the same libamdhip64 (two runtimes in one process: the second one finds "no ROCm-capable device")
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
