@@ -171,9 +171,15 @@ int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d
  * cleaners (n >= 9).  work = algorithmic FLOPs (0,1,4) / bytes (6,8) summed over the launches since r3g_prof_enable(1). */
 int r3g_prof_enable(int on);
 int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
-/* A/B switches for tests and ablations (defaults 1): "fuse_qkv" (QKV split/norm/transpose in the projection
- * epilogue vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch),
- * "lds_dma" (= r3g_set_staging), "cfg_dedup", "gemm_waves" (0 auto | 4 | 8 | 16), "gemm_raster". */
+/* A/B switches for tests and ablations.  Default 1: "fuse_qkv" (QKV split/norm/transpose in the projection epilogue
+ * vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch), "lds_dma"
+ * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
+ * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (MLP half of a single block's linear1
+ * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
+ * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 tile | 10 = 256x128 | 16 | 32 = deep ring), "gemm_raster"
+ * (-1 auto | tile columns per rasterisation group), "attn_pipelined" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per
+ * wave in the marching-cubes row kernel).  None of them changes a result bit, except fuse_qkv / batch_mods / cfg_dedup
+ * (different summation order, same function). */
 int r3g_set_option(const char* name, int value);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);
