@@ -681,6 +681,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 
 static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
+int g_gemm_auto_rule = 1, g_num_cu = 256;
 bool g_gemm_wide_epilogue = true;
 
 template <int EPI>
@@ -691,8 +692,18 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
         // flop) win for long K or very many tiles; 128x128 with 8 waves wins slightly for N <= 1024, 4 waves otherwise
         const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-        if (p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
-        else waves = p.N <= 1024 ? 8 : 4;
+        const long rounds = (t256 + g_num_cu - 1) / g_num_cu;
+        const bool fills = t256 * 10 >= rounds * g_num_cu * 9;   // the last dispatch round of 256x256 tiles is >= 90 % full
+        if (g_gemm_auto_rule == 0) {
+            if (p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048)) waves = 9;
+            else waves = p.N <= 1024 ? 8 : 4;
+        } else {
+            // A CU keeps ~20 B/clk of operand loads in flight (L1 miss queue x L2 latency, profiles/r01_pmc_gemm_counters.md):
+            // the 256x256 tile needs half the bytes per flop of the 128x128 one and wins wherever its coarser grid
+            // still fills the machine; otherwise 128x128 with 8 waves (4 per SIMD at two workgroups per CU).
+            if (p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills))) waves = 9;
+            else waves = 8;
+        }
     }
     if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, p2, glds, s);
@@ -707,6 +718,10 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 static bool g_gemm_glds = true;
 void gemm_set_glds(bool on) { g_gemm_glds = on; }
 void gemm_set_raster(int group) { g_gemm_raster = group; }
+void gemm_set_auto_rule(int rule, int num_cu) {
+    if (rule >= 0) g_gemm_auto_rule = rule;
+    if (num_cu > 0) g_num_cu = num_cu;
+}
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_config(int waves, int stages) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 16 || waves == 32) g_gemm_waves = waves;

@@ -65,6 +65,7 @@ void attn_set_glds(bool on);
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
 void gemm_set_config(int waves, int stages);
 void gemm_set_raster(int group);
+void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)

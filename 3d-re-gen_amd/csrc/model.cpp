@@ -927,6 +927,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);
     else if (!strcmp(name, "gemm_stages")) gemm_set_config(0, value);
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);
+    else if (!strcmp(name, "gemm_auto_rule")) gemm_set_auto_rule(value, 0);
     else if (!strcmp(name, "gemm_wide_epilogue")) gemm_set_wide_epilogue(value != 0);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "mc_rows")) mc_set_rows_per_wave(value);

@@ -68,6 +68,7 @@ int r3g_create(int device, r3g_ctx** out) {
     if (!c) return fail(R3G_ERR_HIP, "out of host memory");
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    gemm_set_auto_rule(-1, c->num_cu);
     e = hipHostMalloc((void**)&c->h_small, 64, hipHostMallocDefault);
     if (e != hipSuccess) {
         delete c;

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "kernels.h"
 #include "mc_kernels.h"
 
 namespace r3g {
