@@ -691,7 +691,8 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
     if (waves == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
         // flop) win for long K or very many tiles; 128x128 with 8 waves wins slightly for N <= 1024, 4 waves otherwise
-        const long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
+        long t256 = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
+        if (p2.M > 0) t256 += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
         const long rounds = (t256 + g_num_cu - 1) / g_num_cu;
         const bool fills = t256 * 10 >= rounds * g_num_cu * 9;   // the last dispatch round of 256x256 tiles is >= 90 % full
         if (g_gemm_auto_rule == 0) {
@@ -701,7 +702,8 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             // A CU keeps ~20 B/clk of operand loads in flight (L1 miss queue x L2 latency, profiles/r01_pmc_gemm_counters.md):
             // the 256x256 tile needs half the bytes per flop of the 128x128 one and wins wherever its coarser grid
             // still fills the machine; otherwise 128x128 with 8 waves (4 per SIMD at two workgroups per CU).
-            if (p2.M == 0 && p.N % 256 == 0 && t256 >= 128 && (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills))) waves = 9;
+            if ((p2.M == 0 || p2.N % 256 == 0) && p.N % 256 == 0 && t256 >= 128 &&
+                (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills))) waves = 9;
             else waves = 8;
         }
     }
