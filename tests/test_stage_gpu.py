@@ -41,3 +41,29 @@ def test_stage_script_writes_glbs(tmp_path):
         m = load_glb(str(out / stem / (stem + ".glb")))
         assert len(m.faces) > 0 and len(m.faces) <= 40000          # FaceReducer bound
         assert np.isfinite(m.vertices).all() and np.abs(m.vertices).max() <= 1.02
+
+
+def test_octree_resolution_512_end_to_end():
+    """SURVEY config 4's grid size (513^3 = 135 M points, a 15 M-vertex mesh) through grid query, marching cubes and the
+    cleaners, on tiny model dims so that it takes seconds; marching cubes still bit-exact against the oracle."""
+    import torch
+    from PIL import Image
+    from hy3dgen.shapegen import DegenerateFaceRemover, FaceReducer, FloaterRemover, Hunyuan3DDiTFlowMatchingPipeline
+    from oracle import hy3d_torch as H, mc as omc
+    cfg = H.tiny_config()
+    sd = {k: (t.to(torch.bfloat16).float() if t.ndim >= 2 else t) for k, t in H.synthetic_state_dict(cfg, seed=5).items()}
+    pipe = Hunyuan3DDiTFlowMatchingPipeline(cfg, sd, "cuda:0")
+    rng = np.random.default_rng(0)
+    arr = np.zeros((80, 80, 4), np.uint8)
+    arr[20:60, 15:65, :3] = rng.integers(0, 255, (40, 50, 3))
+    arr[20:60, 15:65, 3] = 255
+    mesh = pipe(image=Image.fromarray(arr, "RGBA"), num_inference_steps=3, octree_resolution=512,
+                generator=torch.manual_seed(1234567))[0]
+    grid = pipe.last_grid.cpu().numpy()
+    assert grid.shape == (513, 513, 513)
+    ov, of = omc.hy3d_mesh(grid, 0.0, 1.01, 512)
+    assert mesh.n_faces == len(of) > 1000000
+    assert np.array_equal(mesh.faces, of.astype(np.int64))
+    assert np.array_equal(mesh.vertices.astype(np.float32).view(np.uint32), ov.view(np.uint32))
+    small = FaceReducer()(DegenerateFaceRemover()(FloaterRemover()(mesh)))
+    assert 0 < small.n_faces <= 40000
