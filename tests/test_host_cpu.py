@@ -107,3 +107,27 @@ def test_preprocess_product_equals_oracle():
     assert torch.allclose(x, y, atol=1e-6)
     with pytest.raises(ValueError):
         ImageProcessorV2(64, 0.15)(Image.fromarray(np.zeros((8, 8, 4), np.uint8), "RGBA"))
+
+
+def test_cleaner_oracle_properties():
+    """size-independent properties of the restated cleaners on random triangle soups: outputs index densely into
+    their vertex arrays, are idempotent, never grow, and the face budget holds"""
+    from oracle import mesh_clean
+    rng = np.random.default_rng(11)
+    for nv, nf in ((30, 200), (400, 3000), (2000, 9000)):
+        v = rng.standard_normal((nv, 3)).astype(np.float32)
+        f = rng.integers(0, nv, (nf, 3)).astype(np.int32)
+        f[::5, 2] = f[::5, 0]
+        for fn, args in ((mesh_clean.remove_degenerate, ()), (mesh_clean.remove_floaters, (0.2,)),
+                         (mesh_clean.reduce_faces, (nf // 8,))):
+            a, b = fn(v, f, *args)
+            assert a.dtype == np.float32 and b.dtype == np.int32
+            assert len(b) <= nf and len(a) <= nv
+            if len(b):
+                assert b.min() == 0 and b.max() == len(a) - 1 and len(np.unique(b)) == len(a)
+            a2, b2 = fn(a, b, *args)
+            assert np.array_equal(a2, a) and np.array_equal(b2, b)
+        _, rf = mesh_clean.reduce_faces(v, f, nf // 8)
+        assert len(rf) <= nf // 8
+        dv, df = mesh_clean.remove_degenerate(v, f)
+        assert ((df[:, 0] != df[:, 1]) & (df[:, 1] != df[:, 2]) & (df[:, 0] != df[:, 2])).all()

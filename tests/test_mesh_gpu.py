@@ -112,3 +112,35 @@ def test_postprocessor_classes_keep_the_mesh_on_the_gpu():
     assert np.array_equal(h.faces, w2[1])
     data = h.export(file_type="glb")
     assert data[:4] == b"glTF"
+
+
+def test_full_size_properties():
+    """At the size of a dense 257^3 extraction (millions of vertices) the cleaners are checked through size-independent
+    properties: dense vertex indexing, idempotence, the face budget, and agreement of the survivors with the input."""
+    from r3g import mc, meshops
+    g = torch.Generator().manual_seed(3)
+    lo = torch.randn(1, 1, 33, 33, 33, generator=g)
+    vol = torch.nn.functional.interpolate(lo, size=(257, 257, 257), mode="trilinear", align_corners=True)[0, 0]
+    v, f = mc.extract_mesh(vol.cuda().contiguous(), 0.0, 1.01, 256)
+    assert v.shape[0] > 1000000
+    for fn, args in ((meshops.remove_floaters, (0.005,)), (meshops.remove_degenerate, ()), (meshops.reduce_faces, (40000,))):
+        a, b = fn(v, f, *args)
+        assert 0 < b.shape[0] <= f.shape[0] and a.shape[0] <= v.shape[0]
+        u = torch.unique(b)
+        assert u.numel() == a.shape[0] and int(u[0]) == 0 and int(u[-1]) == a.shape[0] - 1
+        a2, b2 = fn(a, b, *args)
+        assert torch.equal(a2, a) and torch.equal(b2, b)
+    fv, ff = meshops.remove_floaters(v, f, 0.005)
+    # survivors are input faces, in input order, with their vertices' coordinates unchanged
+    tri_in = v[f.long()].reshape(-1, 9)
+    tri_out = fv[ff.long()].reshape(-1, 9)
+    idx = torch.arange(0, tri_out.shape[0], max(1, tri_out.shape[0] // 4096), device="cuda")
+    first = tri_out[idx]
+    # every sampled output triangle occurs in the input (compared through a position-weighted checksum)
+    h_in = (tri_in * torch.arange(1, 10, device="cuda")).sum(1)
+    h_out = (first * torch.arange(1, 10, device="cuda")).sum(1)
+    assert torch.isin(h_out, h_in).all()
+    rv, rf = meshops.reduce_faces(fv, ff, 40000)
+    assert rf.shape[0] <= 40000
+    lo_b, hi_b = fv.min(0).values, fv.max(0).values
+    assert (rv >= lo_b - 1e-6).all() and (rv <= hi_b + 1e-6).all()      # cluster means stay inside the bounding box
