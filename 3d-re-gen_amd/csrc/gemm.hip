@@ -752,7 +752,14 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
         return hipSuccess;
     }
     if (!gemm_args_ok(p)) return hipErrorInvalidValue;
-    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s);
+    // algorithmic bytes of a launch: each operand read once, the result written once (fp32 residual: read + written)
+    auto alg_bytes = [](const GemmArgs& g) {
+        if (g.M <= 0) return 0.0;
+        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 ? 4.0 : 2.0);
+        return (double)g.batch * (2.0 * g.M * g.K + out * (double)g.M * g.N) + 2.0 * (double)g.N * g.K;
+    };
+    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
+                 alg_bytes(p) + alg_bytes(p2));
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, p2, g_gemm_glds, s);
         case EPI_BF16_GELU_TANH: return launch_epi<EPI_BF16_GELU_TANH>(p, p2, g_gemm_glds, s);

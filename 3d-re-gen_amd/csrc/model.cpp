@@ -917,6 +917,12 @@ int r3g_prof_read(int64_t* counts, double* ms, double* work, int n) {
     return R3G_OK;
 }
 
+int r3g_prof_read_bytes(double* bytes, int n) {
+    if (!bytes || n < PC_COUNT) return fail(R3G_ERR_INVALID, "r3g_prof_read_bytes: need %d slots", (int)PC_COUNT);
+    prof_read_bytes(bytes);
+    return R3G_OK;
+}
+
 int r3g_set_option(const char* name, int value) {
     if (!name) return fail(R3G_ERR_INVALID, "r3g_set_option: null name");
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;

@@ -5,13 +5,13 @@
 
 namespace r3g {
 namespace {
-struct Rec { hipEvent_t a, b; int cat; double work; };
+struct Rec { hipEvent_t a, b; int cat; double work, bytes; };
 constexpr int kRing = 2048;
 bool g_on = false;
 std::vector<Rec> g_ring;
 int g_used = 0;
 long long g_cnt[PC_COUNT];
-double g_ms[PC_COUNT], g_work[PC_COUNT];
+double g_ms[PC_COUNT], g_work[PC_COUNT], g_bytes[PC_COUNT];
 
 void drain() {
     if (g_used == 0) return;
@@ -22,6 +22,7 @@ void drain() {
             g_cnt[g_ring[i].cat] += 1;
             g_ms[g_ring[i].cat] += ms;
             g_work[g_ring[i].cat] += g_ring[i].work;
+            g_bytes[g_ring[i].cat] += g_ring[i].bytes;
         }
     }
     g_used = 0;
@@ -38,7 +39,7 @@ void prof_enable(bool on) {
             }
         }
         g_used = 0;
-        for (int i = 0; i < PC_COUNT; ++i) { g_cnt[i] = 0; g_ms[i] = 0; g_work[i] = 0; }
+        for (int i = 0; i < PC_COUNT; ++i) { g_cnt[i] = 0; g_ms[i] = 0; g_work[i] = 0; g_bytes[i] = 0; }
     } else {
         drain();
     }
@@ -47,12 +48,13 @@ void prof_enable(bool on) {
 
 bool prof_enabled() { return g_on; }
 
-ProfScope::ProfScope(int cat, double work, hipStream_t stream) : slot(-1), s(stream) {
+ProfScope::ProfScope(int cat, double work, hipStream_t stream, double bytes) : slot(-1), s(stream) {
     if (!g_on) return;
     if (g_used == kRing) drain();
     slot = g_used++;
     g_ring[slot].cat = cat;
     g_ring[slot].work = work;
+    g_ring[slot].bytes = bytes;
     (void)hipEventRecord(g_ring[slot].a, s);
 }
 
@@ -67,6 +69,11 @@ void prof_read(long long* counts, double* ms, double* work) {
         ms[i] = g_ms[i];
         work[i] = g_work[i];
     }
+}
+
+void prof_read_bytes(double* bytes) {
+    drain();
+    for (int i = 0; i < PC_COUNT; ++i) bytes[i] = g_bytes[i];
 }
 
 }  // namespace r3g

@@ -11,7 +11,8 @@ enum ProfCat { PC_GEMM = 0, PC_ATTN, PC_LAYERNORM, PC_QKV_SPLIT, PC_GEMV, PC_ELE
 struct ProfScope {
     int slot;
     hipStream_t s;
-    ProfScope(int cat, double work, hipStream_t stream);
+    // bytes: algorithmic operand + result bytes of an MFMA launch (families whose `work` is FLOPs)
+    ProfScope(int cat, double work, hipStream_t stream, double bytes = 0.0);
     ~ProfScope();
 };
 
@@ -19,6 +20,7 @@ void prof_enable(bool on);   // enabling resets the accumulators
 bool prof_enabled();
 // drains outstanding events; fills per-category launch counts, total milliseconds and total work
 void prof_read(long long* counts, double* ms, double* work);
+void prof_read_bytes(double* bytes);   // per category: sum of the `bytes` given to ProfScope
 
 }  // namespace r3g
 #endif

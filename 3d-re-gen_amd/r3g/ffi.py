@@ -53,6 +53,7 @@ SYMBOLS = {
     "r3g_set_option": (_I, [ctypes.c_char_p, _I]),
     "r3g_prof_enable": (_I, [_I]),
     "r3g_prof_read": (_I, [_P, _P, _P, _I]),
+    "r3g_prof_read_bytes": (_I, [_P, _I]),
 }
 
 

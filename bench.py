@@ -222,6 +222,8 @@ def main():
         n = len(FAMILIES)
         cnt, ms, work = (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
         ffi.check(L.r3g_prof_read(cnt, ms, work, n))
+        alg = (ctypes.c_double * n)()
+        ffi.check(L.r3g_prof_read_bytes(alg, n))
         ffi.check(L.r3g_prof_enable(0))
         fam = {FAMILIES[i]: {"launches": int(cnt[i]), "ms": float(ms[i]), "work": float(work[i])} for i in range(n)}
         dom = max(("gemm", "attention"), key=lambda k: fam[k]["ms"])
@@ -229,7 +231,9 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_BF16_TFLOPS,
                            "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if dom == "gemm" else None,
-                           "algorithmic_bytes_per_launch": None, "launches": fam[dom]["launches"],
+                           "algorithmic_bytes_per_launch": (float(alg[FAMILIES.index(dom)]) / max(1, fam[dom]["launches"])
+                                                            if dom == "gemm" else None),
+                           "launches": fam[dom]["launches"],
                            "avg_launch_us": 1000.0 * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
                            "note": "per-launch HIP events on one extra object with overlap_mlp=0 (kernels run alone)",
                            "families_ms_per_object": {k: round(v["ms"], 3) for k, v in fam.items()},

@@ -171,6 +171,8 @@ int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d
  * cleaners (n >= 9).  work = algorithmic FLOPs (0,1,4) / bytes (6,8) summed over the launches since r3g_prof_enable(1). */
 int r3g_prof_enable(int on);
 int r3g_prof_read(int64_t* counts, double* ms, double* work, int n);
+/* per family: algorithmic bytes (operands read once, result written once) of the launches whose `work` is FLOPs */
+int r3g_prof_read_bytes(double* bytes, int n);
 /* A/B switches for tests and ablations.  Default 1: "fuse_qkv" (QKV split/norm/transpose in the projection epilogue
  * vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch), "lds_dma"
  * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
