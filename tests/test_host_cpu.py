@@ -131,3 +131,36 @@ def test_cleaner_oracle_properties():
         assert len(rf) <= nf // 8
         dv, df = mesh_clean.remove_degenerate(v, f)
         assert ((df[:, 0] != df[:, 1]) & (df[:, 1] != df[:, 2]) & (df[:, 0] != df[:, 2])).all()
+
+
+def _snapshot_doc(cfg):
+    """an upstream-style config.yaml document for `cfg` (the keys config_from_yaml reads)"""
+    return {"model": {"target": "hy3dgen.shapegen.models.Hunyuan3DDiT", "params": dict(cfg["dit"])},
+            "vae": {"target": "hy3dgen.shapegen.models.ShapeVAE", "params": dict(cfg["vae"])},
+            "conditioner": {"params": {"main_image_encoder": {"kwargs": {"config": dict(cfg["cond"]),
+                                                                           "image_size": cfg["cond"]["image_size"]}}}},
+            "scheduler": {"params": dict(cfg["sched"])},
+            "image_processor": {"params": dict(cfg["proc"])}}
+
+
+def test_snapshot_config_and_weight_files(tmp_path):
+    """`from_pretrained(<dir>)`'s host half: config.yaml -> cfg, model[.variant].safetensors lookup"""
+    import yaml
+    from safetensors.torch import save_file
+    from hy3dgen.shapegen.pipelines import config_from_yaml
+    from oracle import hy3d_torch as H
+    from r3g import weights as W
+    cfg = H.tiny_config()
+    got = config_from_yaml(yaml.safe_load(yaml.safe_dump(_snapshot_doc(cfg))))
+    for sec in ("dit", "vae", "cond", "sched", "proc"):
+        for k, v in cfg[sec].items():
+            if k in got[sec]:
+                assert got[sec][k] == v, (sec, k)
+    assert got["dit"]["hidden_size"] == 128 and got["vae"]["num_latents"] == 256 and got["cond"]["image_size"] == 70
+    sd = {k: v.contiguous() for k, v in W.synthetic_state_dict(cfg, 0, "cpu").items()}
+    save_file(sd, str(tmp_path / "model.fp16.safetensors"))
+    back = W.load_safetensors_dir(str(tmp_path), "fp16")
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    assert set(W.load_safetensors_dir(str(tmp_path), None)) == set(sd)        # falls back to model.fp16.safetensors
+    with pytest.raises(FileNotFoundError):
+        W.load_safetensors_dir(str(tmp_path / "nope"), "fp16")

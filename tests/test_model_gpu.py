@@ -288,3 +288,36 @@ def test_grouped_stream_launches_are_bit_identical(which, tiny, wide):
     assert torch.equal(a, c)
     for _ in range(3):                                   # and it is stable from run to run
         assert torch.equal(a, st.gpu.flow_sample(lat0.clone(), cond, 2, 5.0))
+
+
+def test_from_pretrained_snapshot_directory(tmp_path):
+    """the reference's entry point (src/2d_to_3d_models/run.py:122-124) on a local snapshot directory:
+    <dir>/<subfolder>/config.yaml + model.fp16.safetensors -> same mesh as the pipeline built from the same tensors"""
+    import torch
+    import yaml
+    from PIL import Image
+    from safetensors.torch import save_file
+    from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
+    from oracle import hy3d_torch as H
+    from test_host_cpu import _snapshot_doc
+    cfg = H.tiny_config()
+    sd = {k: v.contiguous() for k, v in bf16_round_matrices(H.synthetic_state_dict(cfg, seed=5)).items()}
+    sub = tmp_path / "hunyuan3d-dit-v2-0"
+    sub.mkdir()
+    (sub / "config.yaml").write_text(yaml.safe_dump(_snapshot_doc(cfg)))
+    save_file(sd, str(sub / "model.fp16.safetensors"))
+    a = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(str(tmp_path), subfolder="hunyuan3d-dit-v2-0", variant="fp16")
+    rng = np.random.default_rng(2)
+    img = np.zeros((96, 80, 4), np.uint8)
+    img[20:70, 15:60, :3] = rng.integers(0, 255, (50, 45, 3))
+    img[20:70, 15:60, 3] = 255
+    pil = Image.fromarray(img, "RGBA")
+    kw = dict(image=pil, num_inference_steps=3, octree_resolution=24, num_chunks=999, output_type="trimesh")
+    ma = a(generator=torch.manual_seed(7), **kw)[0]
+    ga = a.last_grid.clone()
+    b = Hunyuan3DDiTFlowMatchingPipeline(cfg, sd, "cuda:0")
+    mb = b(generator=torch.manual_seed(7), **kw)[0]
+    assert torch.equal(ga, b.last_grid)
+    assert np.array_equal(ma.faces, mb.faces) and np.array_equal(ma.vertices, mb.vertices)
+    with pytest.raises(FileNotFoundError):
+        Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(str(tmp_path / "missing"))
