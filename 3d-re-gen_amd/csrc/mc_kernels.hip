@@ -40,6 +40,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 1024;  // blocks per scan chunk
+constexpr int kEmitThreads = 64;  // K3 / K4: one wave per non-empty block
 
 __device__ __forceinline__ void cell_coords(uint32_t c, int cx, int cy, int& x, int& y, int& z) {
     const uint32_t row = c / (uint32_t)cx;
@@ -328,38 +329,41 @@ __global__ __launch_bounds__(kChunk) void mc_scan(const uint4* __restrict__ blk,
     }
 }
 
-__global__ __launch_bounds__(kBlock) void mc_vertices(const float* __restrict__ grid, int nx, int ny, int cx, int cy,
+__global__ __launch_bounds__(kEmitThreads) void mc_vertices(const float* __restrict__ grid, int nx, int ny, int cx, int cy,
                                                       double level, const uint2* __restrict__ act,
                                                       const uint4* __restrict__ blk, const uint2* __restrict__ blkoff,
                                                       const uint32_t* __restrict__ nzlist,
                                                       int32_t* __restrict__ etab, float* __restrict__ verts,
                                                       Xform xf, int use_xf) {
+    // one wave per non-empty block: a block of 256 cells holds ~10-30 active cells (at most 256: the loop)
     const uint32_t b = nzlist[blockIdx.x];
-    const unsigned tid = threadIdx.x;
-    if (tid >= blk[b].z) return;
-    const uint2 a = act[(size_t)b * kBlock + tid];
-    const uint32_t c = b * kBlock + (a.y & 0xFFu);
-    int x, y, z;
-    cell_coords(c, cx, cy, x, y, z);
-    emit_cell_vertices(a.x, blkoff[b].x + ((a.y >> 8) & 0xFFFu), grid, level, x, y, z, nx, ny, etab, verts,
-                       xf, use_xf != 0);
+    const unsigned n_act = blk[b].z;
+    const uint32_t voff = blkoff[b].x;
+    for (unsigned tid = threadIdx.x; tid < n_act; tid += kEmitThreads) {
+        const uint2 a = act[(size_t)b * kBlock + tid];
+        const uint32_t c = b * kBlock + (a.y & 0xFFu);
+        int x, y, z;
+        cell_coords(c, cx, cy, x, y, z);
+        emit_cell_vertices(a.x, voff + ((a.y >> 8) & 0xFFFu), grid, level, x, y, z, nx, ny, etab, verts, xf, use_xf != 0);
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void mc_faces(int nx, int ny, int cx, int cy, const uint2* __restrict__ act,
+__global__ __launch_bounds__(kEmitThreads) void mc_faces(int nx, int ny, int cx, int cy, const uint2* __restrict__ act,
                                                    const uint4* __restrict__ blk, const uint2* __restrict__ blkoff,
                                                    const uint32_t* __restrict__ nzlist,
                                                    const int32_t* __restrict__ etab, int32_t* __restrict__ faces,
                                                    int reversed) {
     const uint32_t b = nzlist[blockIdx.x];
-    const unsigned tid = threadIdx.x;
-    if (tid >= blk[b].z) return;
-    const uint2 a = act[(size_t)b * kBlock + tid];
-    const uint32_t c = b * kBlock + (a.y & 0xFFu);
-    int x, y, z;
-    cell_coords(c, cx, cy, x, y, z);
+    const unsigned n_act = blk[b].z;
     const uint2 off = blkoff[b];
-    emit_cell_faces(a.x, off.x + ((a.y >> 8) & 0xFFFu), off.y + (a.y >> 20), x, y, z, nx, ny, etab, faces,
-                    reversed != 0);
+    for (unsigned tid = threadIdx.x; tid < n_act; tid += kEmitThreads) {
+        const uint2 a = act[(size_t)b * kBlock + tid];
+        const uint32_t c = b * kBlock + (a.y & 0xFFu);
+        int x, y, z;
+        cell_coords(c, cx, cy, x, y, z);
+        emit_cell_faces(a.x, off.x + ((a.y >> 8) & 0xFFFu), off.y + (a.y >> 20), x, y, z, nx, ny, etab, faces,
+                        reversed != 0);
+    }
 }
 
 }  // namespace
@@ -442,10 +446,10 @@ hipError_t mc_emit_launch(const float* grid, int n0, int n1, int n2, double leve
     }
     ProfScope ps(PC_MC_OTHER, 0.0, stream);
     const uint32_t* nz = (const uint32_t*)(ws + lay.off_nz);
-    hipLaunchKernelGGL(mc_vertices, dim3(lay.nnz), dim3(kBlock), 0, stream, grid, nx, ny, cx, cy, level,
+    hipLaunchKernelGGL(mc_vertices, dim3(lay.nnz), dim3(kEmitThreads), 0, stream, grid, nx, ny, cx, cy, level,
                        (const uint2*)(ws + lay.off_act), (const uint4*)(ws + lay.off_blk),
                        (const uint2*)(ws + lay.off_blkoff), nz, (int32_t*)(ws + lay.off_etab), verts, xf, xf9 ? 1 : 0);
-    hipLaunchKernelGGL(mc_faces, dim3(lay.nnz), dim3(kBlock), 0, stream, nx, ny, cx, cy,
+    hipLaunchKernelGGL(mc_faces, dim3(lay.nnz), dim3(kEmitThreads), 0, stream, nx, ny, cx, cy,
                        (const uint2*)(ws + lay.off_act), (const uint4*)(ws + lay.off_blk),
                        (const uint2*)(ws + lay.off_blkoff), nz, (const int32_t*)(ws + lay.off_etab), faces, reversed);
     return hipGetLastError();
