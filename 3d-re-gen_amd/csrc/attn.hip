@@ -212,18 +212,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < Lq) {
+    // Output: lane (q, hh) holds dims db*32 + 8g + 4hh + {0..3} of query q.  The two lanes of a query swap halves so
+    // that each writes 8 consecutive dims: 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail of a
+    // workgroup is issue bound).  The exchange runs for every lane (a padded query's partner is padded too).
+    {
         int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
         if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
         uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-                pk.y = pack_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(dst + db * 32 + 8 * g + 4 * hh) = pk;
+            for (int gp = 0; gp < 2; ++gp) {
+                uint2 even, odd;   // this lane's packed dims of g = 2gp and g = 2gp + 1
+                even.x = pack_bf16(o[db][8 * gp] * inv, o[db][8 * gp + 1] * inv);
+                even.y = pack_bf16(o[db][8 * gp + 2] * inv, o[db][8 * gp + 3] * inv);
+                odd.x = pack_bf16(o[db][8 * gp + 4] * inv, o[db][8 * gp + 5] * inv);
+                odd.y = pack_bf16(o[db][8 * gp + 6] * inv, o[db][8 * gp + 7] * inv);
+                // hh = 0 keeps `even` and receives the partner's `even` (dims +4..7); hh = 1 keeps `odd`, receives `odd`
+                const uint2 give = hh ? even : odd;
+                uint2 got;
+                got.x = (uint32_t)__shfl_xor((int)give.x, 32, 64);
+                got.y = (uint32_t)__shfl_xor((int)give.y, 32, 64);
+                const uint2 mine = hh ? odd : even;
+                uint4 out;
+                if (hh) { out.x = got.x; out.y = got.y; out.z = mine.x; out.w = mine.y; }
+                else { out.x = mine.x; out.y = mine.y; out.z = got.x; out.w = got.y; }
+                if (q < Lq) *reinterpret_cast<uint4*>(dst + db * 32 + 16 * gp + 8 * hh) = out;
             }
     }
 }
