@@ -458,7 +458,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs pa, GemmArgs pb)
     // L2-friendly rasterisation: tiles are walked in groups of GN tile-columns, row-major inside a group, so the ~64
     // tiles resident on one XCD span ~8 tile-rows x 8 tile-columns (A and W panels of a group stay in the 4 MiB L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int rg = p.raster_group < 0 ? (BIG == 1 ? 4 : 0) : p.raster_group;   // <0: automatic
+    // automatic: 4-column groups for 256x256 tiles and for wide 128x128 grids (>= 16 tile columns; run 32: +2..7 %)
+    const int rg = p.raster_group < 0 ? ((BIG == 1 || tiles_n >= 16) ? 4 : 0) : p.raster_group;
     const int GN = rg > 0 ? rg : tiles_n;  // 0: plain row-major tile order
     const int rows_all = tiles_m * p.batch;  // (batch, tm) flattened
     const int per_group = rows_all * GN;
