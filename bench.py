@@ -41,7 +41,7 @@ PEAK_HBM_GBPS = 8000.0
 # HBM-side traffic of the GEMM family per launch, from rocprofv3 PMC passes (profiles/r01_pmc_traffic.md): FETCH_SIZE and
 # WRITE_SIZE collected in separate passes, FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16-byte
 # loads, MI355X_MICROARCH.md "HBM"), per-variant averages weighted by the launch counts of one 50-step object.
-GEMM_TRAFFIC_BYTES_PER_LAUNCH = 2.68e8
+GEMM_TRAFFIC_BYTES_PER_LAUNCH = 2.54e8
 FAMILIES = ["gemm", "attention", "layernorm", "qkv_split", "gemv", "elementwise", "mc_classify", "mc_other", "mesh"]
 
 
