@@ -164,3 +164,24 @@ def test_snapshot_config_and_weight_files(tmp_path):
     assert set(W.load_safetensors_dir(str(tmp_path), None)) == set(sd)        # falls back to model.fp16.safetensors
     with pytest.raises(FileNotFoundError):
         W.load_safetensors_dir(str(tmp_path / "nope"), "fp16")
+
+
+def test_bench_workload_definition():
+    """bench.py's synthetic workload: the FLOP budget of configs[1] and the seeded crops"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from hy3dgen.shapegen.pipelines import builtin_config
+    f = bench.flops_per_object(builtin_config("full"), 50, 256)
+    assert abs(f / 1.498e15 - 1.0) < 2e-3                     # DiT 925.1 T + VAE 1.86 T + grid query 571.4 T
+    assert abs(bench.flops_per_object(builtin_config("full"), 1, 256) - (f - 49 * 2 * 9.251e12)) / f < 1e-3
+    a, b = bench.synthetic_crop(3), bench.synthetic_crop(3)
+    assert a.mode == "RGBA" and a.size == (512, 512) and a.tobytes() == b.tobytes()      # seeded, reproducible
+    assert bench.synthetic_crop(4).tobytes() != a.tobytes()
+    for i in range(6):
+        al = np.asarray(bench.synthetic_crop(i))[..., 3]
+        cov = (al > 0).mean()
+        assert 0.25 <= cov <= 0.85, (i, cov)
+        rgb = np.asarray(bench.synthetic_crop(i))[..., :3]
+        assert (rgb[al == 0] == 255).all()                     # white where transparent
