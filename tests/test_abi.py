@@ -48,3 +48,42 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), (d, f)
                 assert "oracle/" not in txt.replace("never includes anything from oracle/", ""), (d, f)
+
+
+def test_binding_matches_the_prototypes():
+    """every prototype of include/r3g.h against the ctypes table: number of parameters, and pointer / integer /
+    floating kind of each one (a drifted binding corrupts the call instead of failing)"""
+    import ctypes
+    from r3g import ffi
+    txt = open(os.path.join(ROOT, "include", "r3g.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = re.findall(r"\b([a-z_0-9 ]+?[\s\*]+)(r3g_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", txt, flags=re.S)
+    assert len(protos) == len(ffi.SYMBOLS)
+
+    def kind_c(param):
+        p = " ".join(param.split())
+        if "*" in p:
+            return "ptr"
+        if re.search(r"\b(double|float)\b", p):
+            return "flt"
+        return "int"
+
+    def kind_py(t):
+        if t in (ctypes.c_double, ctypes.c_float):
+            return "flt"
+        if t in (ctypes.c_int, ctypes.c_int64, ctypes.c_int32):
+            return "int"
+        return "ptr"       # c_void_p, c_char_p, POINTER(...)
+
+    for ret, name, params in protos:
+        params = params.strip()
+        plist = [] if params in ("", "void") else [q for q in params.split(",")]
+        res, args = ffi.SYMBOLS[name]
+        assert len(plist) == len(args), name
+        assert [kind_c(q) for q in plist] == [kind_py(t) for t in args], name
+        if "*" in ret:
+            assert res is ctypes.c_char_p, name
+        elif "void" in ret:
+            assert res is None, name
+        else:
+            assert res is ctypes.c_int, name
