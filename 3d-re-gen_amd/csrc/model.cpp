@@ -832,6 +832,18 @@ int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint
     return dit_forward(*m, d_x, d_t, 0.f, d_cond, d_out, batch, n_double, n_single, (hipStream_t)stream);
 }
 
+int r3g_dit_stream(r3g_ctx* ctx, float* d_out, int batch, void* stream) {
+    NEED_MODEL("r3g_dit_stream");
+    if (!d_out || batch < 1 || batch > 2) return fail(R3G_ERR_INVALID, "r3g_dit_stream: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t H = m->H, Nl = m->c.vae_num_latents, Lc = m->Lc, T = m->T, xs = (int64_t)m->Tpad * H;
+    for (int b = 0; b < batch; ++b) {   // arena order [latent | cond | pad]  ->  upstream order cat(cond, latent)
+        R3G_TRY(hipMemcpyAsync(d_out + b * T * H, m->f32a + b * xs + Nl * H, (size_t)(Lc * H) * 4, hipMemcpyDeviceToDevice, s));
+        R3G_TRY(hipMemcpyAsync(d_out + b * T * H + Lc * H, m->f32a + b * xs, (size_t)(Nl * H) * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return R3G_OK;
+}
+
 int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
                     float shift, int uncond_uniform, void* stream) {
     NEED_MODEL("r3g_flow_sample");

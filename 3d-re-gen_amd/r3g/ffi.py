@@ -44,6 +44,7 @@ SYMBOLS = {
     "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),
     "r3g_cond_encode": (_I, [_P, _P, _P, _P]),
     "r3g_dit_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "r3g_dit_stream": (_I, [_P, _P, _I, _P]),
     "r3g_flow_sample": (_I, [_P, _P, _P, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
     "r3g_vae_decode": (_I, [_P, _P, _P, _P]),
     "r3g_grid_query": (_I, [_P, _D, _I, _P, ctypes.c_int64, ctypes.c_int64, _P]),

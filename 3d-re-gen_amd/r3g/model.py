@@ -152,6 +152,14 @@ class ShapeModel:
                                             x.shape[0], n_double, n_single, self._s()))
         return out
 
+    def dit_stream(self, batch):
+        """joint residual stream left by the last dit_forward(): f32 [B, cond_tokens + num_latents, hidden], cond first"""
+        out = torch.empty((batch, self.cond_tokens + self.num_latents, self.cfg["dit"]["hidden_size"]),
+                          dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_dit_stream(self.ctx, out.data_ptr(), int(batch), self._s()))
+        return out
+
     def flow_sample(self, latents, cond2, steps, guidance_scale, shift=1.0, uncond_uniform=None):
         """latents f32 [N,C] (modified in place and returned), cond2 bf16 [2,Lc,D] = [cond, uncond].
         uncond_uniform: all unconditional tokens identical (None = check on the device)."""

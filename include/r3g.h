@@ -136,6 +136,12 @@ int r3g_cond_encode(r3g_ctx* ctx, const float* d_image, uint16_t* d_cond_out, vo
 int r3g_dit_forward(r3g_ctx* ctx, const float* d_x, const float* d_t, const uint16_t* d_cond, float* d_out, int batch,
                     int n_double, int n_single, void* stream);
 
+/* The joint residual stream the preceding r3g_dit_forward(batch, n_double, n_single) left behind, i.e. the input of
+ * the next block (or of final_layer): d_out f32 [batch][cond_tokens + num_latents][hidden] in upstream's order
+ * cat(cond, latent).  For per-block parity tests: (stream after k+1 blocks) - (stream after k blocks) is block k's
+ * branch contribution (hunyuan3ddit.py DoubleStreamBlock / SingleStreamBlock.forward). */
+int r3g_dit_stream(r3g_ctx* ctx, float* d_out, int batch, void* stream);
+
 /* The denoising loop of Hunyuan3DDiTFlowMatchingPipeline.__call__ with classifier-free guidance:
  * sigmas = linspace(0,1,steps) (+ FlowMatchEulerDiscreteScheduler shift), per step
  *   v = DiT(cat([x]*2), sigma, d_cond2);  v = v_u + g (v_c - v_u);  x += (sigma_next - sigma) v

@@ -35,3 +35,24 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """measured parity errors of the GPU tests next to their tolerances (also written to gpurun_out/parity_measured.json)"""
+    try:
+        import parity_support
+    except Exception:
+        return
+    if not parity_support.MEASURED:
+        return
+    terminalreporter.write_line("parity (measured / tolerance):")
+    for name, v, tol in parity_support.MEASURED:
+        terminalreporter.write_line("  %-44s %.3e / %.1e" % (name, v, tol))
+    try:
+        import json
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.json"), "w") as f:
+            json.dump([{"name": n, "value": v, "tol": t} for n, v, t in parity_support.MEASURED], f, indent=1)
+    except OSError:
+        pass

@@ -3,32 +3,18 @@ PyTorch-CPU fp32 restatement oracle/hy3d_torch.py on identical seeded synthetic 
 
 The checkpoint (weights) is bf16-representable on both sides (matrices are rounded to bf16 once, as a real
 bf16 checkpoint would be), so the differences measured here are kernel arithmetic only:
-bf16 GEMM operands / fp32 accumulation / fp32 residual stream.  Stated tolerances:
-  conditioner tokens rel-L2 <= 2e-2, DiT block / full forward rel-L2 <= 1e-2 (tiny) / 2e-2 (full width),
-  N-step latents rel-L2 <= 3e-2, VAE latents rel-L2 <= 2e-2, grid logits max|d| <= 3e-2 * max|logit|.
+bf16 GEMM operands / fp32 accumulation / fp32 residual stream.  The checkpoint is the "unit" one of
+oracle.hy3d_torch.synthetic_state_dict: every branch contributes O(1) to its residual stream, so that a wiring error
+inside a block is far outside the tolerances.  Tolerances live in tests/parity_support.py (TOL) and
+tests/test_mutation_cpu.py proves, hazard by hazard, that a mis-wired block moves the same metric by >= 5x of them.
+Measured values are reported in the pytest terminal summary (tests/conftest.py).
 """
 import numpy as np
 import pytest
 
+from parity_support import TOL, bf16_round_matrices, rel_l2, report
+
 pytestmark = pytest.mark.gpu
-
-
-def rel_l2(a, b):
-    import torch
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float(torch.linalg.norm(a - b) / (torch.linalg.norm(b) + 1e-30))
-
-
-def bf16_round_matrices(sd):
-    import torch
-    out = {}
-    for k, v in sd.items():
-        if torch.is_floating_point(v) and v.ndim >= 2 and not k.endswith(("cls_token", "mask_token", "position_embeddings",
-                                                                         "output_proj.weight")):
-            out[k] = v.to(torch.bfloat16).to(torch.float32)
-        else:
-            out[k] = v.clone()
-    return out
 
 
 class Setup:
@@ -51,15 +37,55 @@ def tiny():
 
 
 def _inputs(s, seed=0):
+    from parity_support import dit_inputs
+    return dit_inputs(s.cfg, seed)
+
+
+def _block_deltas(s, x, t, cond, tag):
+    """For every block k: the GPU's branch contribution stream_{k+1} - stream_k against the oracle block applied to the
+    GPU's OWN stream_k (so the comparison isolates block k; nothing accumulated upstream of it enters)."""
     import torch
-    g = torch.Generator().manual_seed(seed)
-    d = s.cfg["dit"]
-    Lc = (s.cfg["cond"]["image_size"] // s.cfg["cond"]["patch_size"]) ** 2 + 1
-    x = torch.randn(2, s.cfg["vae"]["num_latents"], d["in_channels"], generator=g)
-    cond = torch.randn(2, Lc, d["context_in_dim"], generator=g).to(torch.bfloat16).float()
-    cond[1] = 0
-    t = torch.tensor([0.37, 0.37])
-    return x, t, cond
+    import parity_support as P
+    m = s.oracle.model
+    nd, ns = len(m.double_blocks), len(m.single_blocks)
+    B, n_cond = x.shape[0], cond.shape[1]
+    _, _, vec = P.dit_prologue(m, x, t, cond)
+    streams = []
+    for k in range(nd + ns + 1):
+        s.gpu.dit_forward(x, t, cond, min(k, nd), max(0, k - nd))
+        streams.append(s.gpu.dit_stream(B).cpu())
+    worst = 0.0
+    for k in range(nd + ns):
+        ref = P.dit_block_apply(m, k, streams[k], vec, n_cond) - streams[k]
+        got = streams[k + 1] - streams[k]
+        assert torch.isfinite(got).all()
+        err = P.block_delta_error(got, ref, n_cond, k < nd)
+        # branch contributions are O(1) of the stream: a near-identity block could not pass by accident
+        assert float(ref.norm() / streams[k].norm()) > 0.1
+        report("%s block %2d delta" % (tag, k), err, TOL["block_delta"])
+        worst = max(worst, err)
+    return worst
+
+
+def test_dit_block_deltas_tiny(tiny):
+    x, t, cond = _inputs(tiny)
+    assert _block_deltas(tiny, x, t, cond, "tiny") <= TOL["block_delta"]
+
+
+def test_dit_block_deltas_small_q():
+    """the q/k RMSNorm eps (1e-6): a first-order term only when mean(q^2) ~ eps.  Same blocks on the checkpoint whose
+    q / k rows are scaled by 1e-3 (tests/test_mutation_cpu.py::test_qk_norm_eps_needs_small_q: eps 1e-5, 1e-7 or 0
+    would move these contributions by >= 5x the tolerance)."""
+    import parity_support as P
+    from oracle import hy3d_torch as H
+    s = Setup.__new__(Setup)
+    from r3g import model as M
+    s.cfg = H.tiny_config()
+    s.sd = P.small_qk_state_dict(bf16_round_matrices(H.synthetic_state_dict(s.cfg, seed=3)), s.cfg)
+    s.oracle = H.load_state_dict(H.ShapePipeline(s.cfg), s.sd)
+    s.gpu = M.ShapeModel(s.cfg, s.sd, 0, grid_chunk=4096)
+    x, t, cond = P.dit_inputs(s.cfg, 0)
+    assert _block_deltas(s, x, t, cond, "small-q") <= TOL["block_delta"]
 
 
 def test_conditioner_tokens(tiny):
@@ -69,7 +95,9 @@ def test_conditioner_tokens(tiny):
     img = torch.randn(3, S, S, generator=g)
     ref = tiny.oracle.conditioner.main_image_encoder.model(img[None]).last_hidden_state[0]
     out = tiny.gpu.cond_encode(img)
-    assert rel_l2(out.float(), ref) <= 2e-2
+    err = rel_l2(out.float(), ref)
+    report("tiny conditioner tokens", err, TOL["conditioner"])
+    assert err <= TOL["conditioner"]
 
 
 @pytest.mark.parametrize("nd,ns", [(0, 0), (1, 0), (2, 0), (2, 1), (-1, -1)])
@@ -80,7 +108,9 @@ def test_dit_forward_blocks(tiny, nd, ns):
         ref = tiny.oracle.model(x, t, cond, n_double=None if nd < 0 else nd, n_single=None if ns < 0 else ns)
     out = tiny.gpu.dit_forward(x, t, cond, nd, ns)
     assert torch.isfinite(out).all()
-    assert rel_l2(out, ref) <= 1e-2
+    err = rel_l2(out, ref)
+    report("tiny dit forward nd=%d ns=%d" % (nd, ns), err, TOL["dit_forward_tiny"])
+    assert err <= TOL["dit_forward_tiny"]
 
 
 def test_dit_forward_batch1(tiny):
@@ -88,7 +118,7 @@ def test_dit_forward_batch1(tiny):
     x, t, cond = _inputs(tiny, 4)
     with torch.no_grad():
         ref = tiny.oracle.model(x[:1], t[:1], cond[:1])
-    assert rel_l2(tiny.gpu.dit_forward(x[:1], t[:1], cond[:1]), ref) <= 1e-2
+    assert rel_l2(tiny.gpu.dit_forward(x[:1], t[:1], cond[:1]), ref) <= TOL["dit_forward_tiny"]
 
 
 def test_flow_sample_matches_restated_scheduler(tiny):
@@ -99,7 +129,9 @@ def test_flow_sample_matches_restated_scheduler(tiny):
     trace = []
     ref = tiny.oracle.sample(cond, lat0[None].clone(), steps, g, trace=trace)[0]
     out = tiny.gpu.flow_sample(lat0.clone(), cond, steps, g)
-    assert rel_l2(out, ref) <= 3e-2
+    err = rel_l2(out, ref)
+    report("tiny flow_sample 6 steps", err, TOL["flow_sample"])
+    assert err <= TOL["flow_sample"]
     # the last Euler step has d_sigma = 0 (sigmas = linspace(0,1,N) + trailing 1), upstream quirk
     assert torch.equal(trace[-1], trace[-2])
 
@@ -112,10 +144,13 @@ def test_vae_and_grid_query(tiny):
     with torch.no_grad():
         grid_ref, z_ref = tiny.oracle.latents_to_grid(lat[None], R, 1000)
     z = tiny.gpu.vae_decode(lat, return_z=True)
-    assert rel_l2(z, z_ref[0]) <= 2e-2
+    err = rel_l2(z, z_ref[0])
+    report("tiny vae latents", err, TOL["vae_latents"])
+    assert err <= TOL["vae_latents"]
     grid = tiny.gpu.grid_query(1.01, R)
-    d = (grid.cpu() - grid_ref).abs().max().item()
-    assert d <= 3e-2 * grid_ref.abs().max().item()
+    d = (grid.cpu() - grid_ref).abs().max().item() / grid_ref.abs().max().item()
+    report("tiny grid logits", d, TOL["grid_logits"])
+    assert d <= TOL["grid_logits"]
     # a sub-range query writes only its own slots and matches the full query exactly
     part = torch.full_like(grid, float("nan"))
     tiny.gpu.grid_query(1.01, R, out=part, start=1000, count=777)
@@ -163,8 +198,9 @@ def test_end_to_end_pipeline_tiny():
     oracle = H.load_state_dict(H.ShapePipeline(cfg), sd)
     _, grid_ref = oracle(pil, num_inference_steps=4, octree_resolution=24, num_chunks=999,
                          generator=torch.manual_seed(1234567))
-    d = np.abs(grid - grid_ref.numpy()).max()
-    assert d <= 5e-2 * np.abs(grid_ref.numpy()).max()
+    d = np.abs(grid - grid_ref.numpy()).max() / np.abs(grid_ref.numpy()).max()
+    report("tiny end-to-end grid (4 steps)", float(d), 5e-2)
+    assert d <= 5e-2
 
 
 @pytest.fixture(scope="module")
@@ -175,14 +211,36 @@ def wide():
 
 def test_full_width_dit_block_pair(wide):
     """Full widths and token counts of hunyuan3d-dit-v2-0 (hidden 1024, 16 heads, 3072 + 1370 tokens, CFG batch 2),
-    one double + one single block."""
+    one double + one single block: branch contributions block by block, then the velocity."""
     import torch
     x, t, cond = _inputs(wide, 1)
+    assert _block_deltas(wide, x, t, cond, "full-width") <= TOL["block_delta"]
     with torch.no_grad():
         ref = wide.oracle.model(x, t, cond)
     out = wide.gpu.dit_forward(x, t, cond)
     assert torch.isfinite(out).all()
-    assert rel_l2(out, ref) <= 2e-2
+    err = rel_l2(out, ref)
+    report("full-width 1+1 dit forward", err, TOL["dit_forward_tiny"])
+    assert err <= TOL["dit_forward_tiny"]
+
+
+def test_full_depth_dit_forward():
+    """hunyuan3d-dit-v2-0 at full width AND full depth (16 double + 32 single blocks, 4442 tokens), one velocity
+    evaluation: every block's branch contribution against the oracle block on the same input, and the final velocity
+    against the oracle's own forward.  Batch 1 (the CFG batch is covered at depth 1+1 above and by flow_sample)."""
+    import torch
+    from oracle import hy3d_torch as H
+    from parity_support import dit_inputs
+    s = Setup(H.wide_config(depth=16, depth_single=32, vae_layers=1, cond_layers=1), 17)
+    x, t, cond = dit_inputs(s.cfg, 3, batch=1)
+    worst = _block_deltas(s, x, t, cond, "full-depth")
+    assert worst <= TOL["block_delta"]
+    with torch.no_grad():
+        ref = s.oracle.model(x, t, cond)
+    out = s.gpu.dit_forward(x, t, cond)
+    err = rel_l2(out, ref)
+    report("full-depth 16+32 dit forward", err, TOL["dit_forward_full_depth"])
+    assert torch.isfinite(out).all() and err <= TOL["dit_forward_full_depth"]
 
 
 def test_full_width_conditioner_vae_and_grid_points(wide):
@@ -191,12 +249,16 @@ def test_full_width_conditioner_vae_and_grid_points(wide):
     img = torch.randn(3, 518, 518, generator=g)
     with torch.no_grad():
         ref = wide.oracle.conditioner.main_image_encoder.model(img[None]).last_hidden_state[0]
-    assert rel_l2(wide.gpu.cond_encode(img).float(), ref) <= 2e-2
+    err = rel_l2(wide.gpu.cond_encode(img).float(), ref)
+    report("full-width conditioner (1 layer)", err, TOL["conditioner"])
+    assert err <= TOL["conditioner"]
     lat = torch.randn(3072, 64, generator=g)
     with torch.no_grad():
         z_ref = wide.oracle.vae(lat[None] / wide.oracle.vae.scale_factor)
     z = wide.gpu.vae_decode(lat, return_z=True)
-    assert rel_l2(z, z_ref[0]) <= 2e-2
+    err = rel_l2(z, z_ref[0])
+    report("full-width vae latents (1 layer)", err, TOL["vae_latents"])
+    assert err <= TOL["vae_latents"]
     # a slice of the real 257^3 grid (reference octree_resolution_hy: 256)
     R, start, count = 256, 257 * 257 * 100 + 12345, 3000
     pts = torch.from_numpy(wide.H.dense_grid_points(1.01, R)[start:start + count])
@@ -205,7 +267,9 @@ def test_full_width_conditioner_vae_and_grid_points(wide):
     out = torch.zeros(257 ** 3, device="cuda")
     wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
     got = out[start:start + count].cpu()
-    assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    d = (got - ref).abs().max().item() / ref.abs().max().item()
+    report("full-width grid logits (257^3 slice)", d, TOL["grid_logits"])
+    assert d <= TOL["grid_logits"]
 
 
 def test_fused_and_unfused_paths_agree(tiny):
@@ -223,10 +287,11 @@ def test_fused_and_unfused_paths_agree(tiny):
         ffi.check(L.r3g_set_option(b"fuse_qkv", 1))
         ffi.check(L.r3g_set_option(b"batch_mods", 1))
     # the unfused path rounds the projection to bf16 before the q/k norm; the fused one normalises in fp32
-    assert rel_l2(a, b) <= 5e-3
+    report("fused vs unfused qkv/mods", rel_l2(a, b), 1e-2)
+    assert rel_l2(a, b) <= 1e-2
     with torch.no_grad():
         ref = tiny.oracle.model(x, t, cond)
-    assert rel_l2(a, ref) <= 1e-2 and rel_l2(b, ref) <= 1e-2
+    assert rel_l2(a, ref) <= TOL["dit_forward_tiny"] and rel_l2(b, ref) <= TOL["dit_forward_tiny"]
 
 
 def test_cfg_dedup_is_the_same_function(tiny):
@@ -242,15 +307,16 @@ def test_cfg_dedup_is_the_same_function(tiny):
         b = tiny.gpu.flow_sample(lat0.clone(), cond, 5, 5.0).clone()
     finally:
         ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
-    assert rel_l2(a, b) <= 5e-3
+    report("cfg dedup vs plain batch (5 steps)", rel_l2(a, b), 1e-2)
+    assert rel_l2(a, b) <= 1e-2
     ref = tiny.oracle.sample(cond, lat0[None].clone(), 5, 5.0)[0]
-    assert rel_l2(a, ref) <= 3e-2 and rel_l2(b, ref) <= 3e-2
+    assert rel_l2(a, ref) <= TOL["flow_sample"] and rel_l2(b, ref) <= TOL["flow_sample"]
     # a non-uniform "unconditional" context must take the general path (auto-detected) and still match the oracle
     cond_nu = cond.clone()
     cond_nu[1] = torch.randn_like(cond_nu[1]).to(torch.bfloat16).float()
     c = tiny.gpu.flow_sample(lat0.clone(), cond_nu, 3, 2.0)
     ref = tiny.oracle.sample(cond_nu, lat0[None].clone(), 3, 2.0)[0]
-    assert rel_l2(c, ref) <= 3e-2
+    assert rel_l2(c, ref) <= TOL["flow_sample"]
 
 
 def test_cfg_dedup_full_width(wide):
@@ -259,7 +325,9 @@ def test_cfg_dedup_full_width(wide):
     lat0 = x[0]
     out = wide.gpu.flow_sample(lat0.clone(), cond, 2, 5.0)
     ref = wide.oracle.sample(cond, lat0[None].clone(), 2, 5.0)[0]
-    assert rel_l2(out, ref) <= 3e-2
+    err = rel_l2(out, ref)
+    report("full-width cfg dedup flow_sample 2 steps", err, TOL["flow_sample"])
+    assert err <= TOL["flow_sample"]
 
 
 @pytest.mark.parametrize("which", ["tiny", "wide"])

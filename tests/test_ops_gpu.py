@@ -136,3 +136,21 @@ def test_attention_forced_rescale(env):
                                  stream(torch)))
     assert rel_l2(o.float(), ref) <= 1e-2
     assert torch.allclose(o.float()[0, 5], Vt[0, 0, :, 400].float(), atol=3e-2)
+
+
+@pytest.mark.parametrize("epi,flavour,other", [(1, "tanh", "erf"), (2, "erf", "tanh")])
+def test_gelu_flavour_is_the_stated_one(env, epi, flavour, other):
+    """tanh- and erf-GELU differ by <= 4.7e-4: less than the bf16 step of most outputs, so no rel-L2 can tell them apart
+    (tests/test_mutation_cpu.py).  With W = identity the epilogue sees x exactly; the binned MEAN error against the stated
+    flavour must vanish (rounding noise averages out) while the other flavour is >= 5x the tolerance away."""
+    torch, L, ffi = env
+    from parity_support import MARGIN, TOL_GELU_STAT, gelu_flavour_statistic
+    M, N = 65536, 64
+    g = torch.Generator(device="cuda").manual_seed(epi)
+    x = (torch.rand(M, N, device="cuda", generator=g) * 2.0 - 3.75).to(torch.bfloat16)     # x in [-3.75, -1.75)
+    w = torch.eye(N, device="cuda").to(torch.bfloat16)
+    c = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ffi.check(L.r3g_op_gemm(x.data_ptr(), N, w.data_ptr(), N, None, c.data_ptr(), N, None, M, N, N, epi, 1, stream(torch)))
+    y, xf = c.float().cpu(), x.float().cpu()
+    assert gelu_flavour_statistic(y, xf, flavour) <= TOL_GELU_STAT
+    assert gelu_flavour_statistic(y, xf, other) >= MARGIN * TOL_GELU_STAT
