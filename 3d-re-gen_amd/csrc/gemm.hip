@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "prof.h"
 
@@ -642,6 +644,235 @@ __global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
     gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Phased kernel: 256x256x64 tile, 8 waves (2 along m x 4 along n, 128x64 per wave), 128 KiB of LDS = 2 k-tile buffers
+// of 4 half-tiles (16 KiB each).  The k-loop is cut into 4 phases per k-tile (8 per iteration of two k-tiles); a phase
+// is {ds_read one register sub-tile, issue the LDS-DMA of ONE half-tile, s_barrier, 16 MFMAs = one accumulator quadrant
+// x K=64, s_barrier}.  The two wave rows run one barrier apart, so that on every SIMD one wave is in its MFMA cluster
+// while its partner reads LDS and issues loads; s_setprio keeps the matrix pipe fed.  LDS-DMA is waited for with a
+// COUNTED vmcnt only (never 0 inside the loop): three half-tiles (48 KiB per CU) stay in flight across the barriers.
+//
+// Half-tiles are cut so that their LDS regions become free as early as possible:
+//   A_h (h = 0,1): for both wave rows, the 64 rows of m-half h        (tile row  = (r>>6)*128 + h*64 + (r&63))
+//   W_h          : for all four wave columns, the 32 columns of n-half h (tile col = (r>>5)*64  + h*32 + (r&31))
+// Per k-tile in buffer b:   phase 1 reads W_0, A_0 -> quadrant (0,0);   phase 2 reads W_1 -> (0,1);
+//                           phase 3 reads A_1 (into A_0's registers) -> (1,1);   phase 4 reads nothing -> (1,0).
+// Staging, one half-tile per phase, three phases ahead of its first reader (tiles t, t+1 of this iteration in
+// buffers 0, 1):  P1 A_1(t+1)->1 | P2 W_0(t+2)->0 | P3 A_0(t+2)->0 | P4 W_1(t+2)->0, vmcnt(6) |
+//                 P5 A_1(t+2)->0 | P6 W_0(t+3)->1 | P7 A_0(t+3)->1 | P8 W_1(t+3)->1, vmcnt(6).
+// Hazards.  WAR: a region is restaged two phases after its last read, except W_0 (one phase): its four reads are
+// issued first in phase 1 and retired by lgkmcnt(8) before that phase's first barrier.  RAW: the wait that retires a
+// staged half-tile sits before the first barrier of phase 4 / 8 of EVERY wave, its readers start in phase 5 / 1.
+// Same LDS image as gemm_kernel inside a half-tile (128-byte rows, chunk ^ ((row>>1)&7) on the source and on the reads).
+#define R3G_BAR() asm volatile("s_barrier" ::: "memory")
+#define R3G_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, MI = 8;
+    constexpr int HALF = 16384, BUF = 4 * HALF;   // buffer: [A_0][A_1][W_0][W_1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
+    const bool second = wg_all >= tiles_a;
+    typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kSecond = (sizeof(GemmArgs) + alignof(GemmArgs) - 1) / alignof(GemmArgs) * alignof(GemmArgs);
+    const GemmArgs& p = *(const GemmArgs*)(const GemmArgs __attribute__((address_space(4)))*)(ka + (second ? kSecond : 0));
+    (void)pb;
+    const int wg = second ? wg_all - tiles_a : wg_all;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int rg = p.raster_group < 0 ? 4 : p.raster_group;
+    const int GN = rg > 0 ? rg : tiles_n;
+    const int rows_all = tiles_m * p.batch;
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // ---- staging sources: this lane's 16-byte chunk of piece (wid*2 + i) of each half-tile, at k = 0
+    const uint16_t* srcA[2][2];
+    const uint16_t* srcW[2][2];
+    {
+        const uint16_t* A = p.A + (int64_t)batch * p.strideA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wid * 2 + i) * 8 + (lane >> 3);        // row inside the half-tile
+            const int kc = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int ga = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+                int gw = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+                ga = ga < p.M ? ga : p.M - 1;
+                gw = gw < p.N ? gw : p.N - 1;
+                srcA[h][i] = A + (int64_t)ga * p.lda + kc * 8;
+                srcW[h][i] = p.W + (int64_t)gw * p.ldw + kc * 8;
+            }
+        }
+    }
+    char* const dst0 = smem + wid * 2048;   // + buffer * BUF + region * HALF + i * 1024
+    auto stage_a = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[h][i] + (int64_t)t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + h * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+    auto stage_w = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[h][i] + (int64_t)t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + (2 + h) * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+
+    // ---- fragment read addresses (bytes inside a half-tile) for the two 32-wide k-steps
+    const int sw = (lane >> 1) & 7;   // == ((row >> 1) & 7): the sub-tile / wave offsets are multiples of 16 rows
+    int offA[2], offW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        offA[kk] = (wr * 64 + (lane & 15)) * 128 + ((((kk << 2) + (lane >> 4)) ^ sw) << 4);
+        offW[kk] = (wc * 32 + (lane & 15)) * 128 + ((((kk << 2) + (lane >> 4)) ^ sw) << 4);
+    }
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], wf0[2][2], wf1[2][2];   // A sub-tile (shared by both m-halves), W_0 and W_1 sub-tiles
+
+    auto read_a = [&](int h, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                af[i][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + h * HALF + i * 2048 + offA[kk]);
+    };
+    auto read_w0 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                wf0[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + 2 * HALF + j * 2048 + offW[kk]);
+    };
+    auto read_w1 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                wf1[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + 3 * HALF + j * 2048 + offW[kk]);
+    };
+    // one accumulator quadrant x K = 64: 16 MFMAs on 8 distinct accumulators per k-step
+    auto mma = [&](auto HA, auto HW) {
+        constexpr int ha = decltype(HA)::value, hw = decltype(HW)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[hw * 2 + j][ha * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        hw ? wf1[j][kk] : wf0[j][kk], af[i][kk], acc[hw * 2 + j][ha * 4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    const int nk = p.K / BK;   // even, >= 2 (checked by the launcher)
+    stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+    stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    R3G_BAR();
+    if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
+
+    // four phases on the k-tile in buffer `b`; FULL: not the last iteration (every staging slot has a tile to load)
+    auto four_phases = [&](auto B, auto FULL, const int t) {
+        constexpr int b = decltype(B)::value;
+        constexpr bool full = decltype(FULL)::value;
+        // tiles staged by these phases: b == 0: A_1(t+1)->1, then W_0, A_0, W_1 of t+2 -> 0
+        //                               b == 1: A_1(t+1)->0, then W_0, A_0, W_1 of t+2 -> 1   (t = the k-tile read here)
+        // phase 1
+        read_w0(b);
+        R3G_SB();
+        read_a(0, b);
+        R3G_SB();
+        if (full || b == 0) stage_a(1, t + 1, b ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // W_0's four reads have returned: it is restaged next phase
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 2
+        read_w1(b);
+        R3G_SB();
+        if (full) stage_w(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 3
+        read_a(1, b);
+        R3G_SB();
+        if (full) stage_a(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 4
+        if (full) {
+            stage_w(1, t + 2, b);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (b == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last iteration: A_1 of the last k-tile
+        }
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+    };
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {
+        four_phases(I0{}, std::true_type{}, t);
+        four_phases(I1{}, std::true_type{}, t + 1);
+    }
+    four_phases(I0{}, std::false_type{}, t);
+    four_phases(I1{}, std::false_type{}, t + 1);
+    if (wr == 0) R3G_BAR();
+
+    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
+}
+
+template <int EPI>
+hipError_t launch_gemm8(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
+    int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+    if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+    const size_t lds = 131072;
+    auto k = gemm8_kernel<EPI>;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p, p2);
+    return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_deep(const GemmArgs& p, int batch, hipStream_t s) {
     const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
@@ -708,6 +939,8 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             else waves = 8;
         }
     }
+    if (waves == 11 && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) return launch_gemm8<EPI>(p, p2, s);   // phased 256x256x64
+    if (waves == 11) waves = 8;
     if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, p2, glds, s);
     if (waves == 9) return launch_cfg<EPI, 8, 1>(p, p2, glds, s);   // 256x256 tile, 8 waves of 128x64
@@ -727,7 +960,7 @@ void gemm_set_auto_rule(int rule, int num_cu) {
 }
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 

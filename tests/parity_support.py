@@ -14,16 +14,19 @@ import torch
 # ---- tolerances used by the -m gpu tests (bf16 GEMM operands / fp32 accumulation against the fp32 oracle) ----------
 TOL = {
     # |delta_gpu - delta_oracle| / |delta_oracle| for ONE block applied to the SAME input stream (delta = block(x) - x)
-    "block_delta": 1e-2,
-    # whole DiT forward (velocity), rel-L2
-    "dit_forward_tiny": 1.5e-2,
-    "dit_forward_full_depth": 3e-2,
-    # N-step CFG sampling (latents), rel-L2
-    "flow_sample": 3e-2,
-    # shape-VAE transformer output, rel-L2; grid logits: max |d| / max |logit|
-    "vae_latents": 2e-2,
-    "grid_logits": 3e-2,
-    "conditioner": 2e-2,
+    # (measured on MI355X, round 2: 2.1e-3 .. 2.9e-3 for all 48 full-width blocks)
+    "block_delta": 5e-3,
+    # whole DiT forward (velocity), rel-L2 (measured 2.1e-3 .. 3.0e-3, full depth 3.0e-3)
+    "dit_forward_tiny": 8e-3,
+    "dit_forward_full_depth": 1e-2,
+    # N-step CFG sampling (latents), rel-L2: guidance 5 amplifies the per-step error (measured 7.5e-3 for 6 steps)
+    "flow_sample": 2e-2,
+    # shape-VAE transformer output, rel-L2 (measured 2.5e-3); grid logits: max |d| / max |logit| (measured 3.2e-3)
+    "vae_latents": 8e-3,
+    "grid_logits": 1e-2,
+    "conditioner": 1e-2,      # measured 3.9e-3
+    # two valid bf16 evaluations of the same sampler (different tile partitions) against each other
+    "same_function": 2e-2,
 }
 MARGIN = 5.0   # a hazard counts as detectable when it moves the metric by >= MARGIN x the tolerance
 

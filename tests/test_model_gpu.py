@@ -199,8 +199,8 @@ def test_end_to_end_pipeline_tiny():
     _, grid_ref = oracle(pil, num_inference_steps=4, octree_resolution=24, num_chunks=999,
                          generator=torch.manual_seed(1234567))
     d = np.abs(grid - grid_ref.numpy()).max() / np.abs(grid_ref.numpy()).max()
-    report("tiny end-to-end grid (4 steps)", float(d), 5e-2)
-    assert d <= 5e-2
+    report("tiny end-to-end grid (4 steps)", float(d), 2e-2)
+    assert d <= 2e-2
 
 
 @pytest.fixture(scope="module")
@@ -287,8 +287,8 @@ def test_fused_and_unfused_paths_agree(tiny):
         ffi.check(L.r3g_set_option(b"fuse_qkv", 1))
         ffi.check(L.r3g_set_option(b"batch_mods", 1))
     # the unfused path rounds the projection to bf16 before the q/k norm; the fused one normalises in fp32
-    report("fused vs unfused qkv/mods", rel_l2(a, b), 1e-2)
-    assert rel_l2(a, b) <= 1e-2
+    report("fused vs unfused qkv/mods", rel_l2(a, b), TOL["dit_forward_tiny"])
+    assert rel_l2(a, b) <= TOL["dit_forward_tiny"]
     with torch.no_grad():
         ref = tiny.oracle.model(x, t, cond)
     assert rel_l2(a, ref) <= TOL["dit_forward_tiny"] and rel_l2(b, ref) <= TOL["dit_forward_tiny"]
@@ -307,8 +307,8 @@ def test_cfg_dedup_is_the_same_function(tiny):
         b = tiny.gpu.flow_sample(lat0.clone(), cond, 5, 5.0).clone()
     finally:
         ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
-    report("cfg dedup vs plain batch (5 steps)", rel_l2(a, b), 1e-2)
-    assert rel_l2(a, b) <= 1e-2
+    report("cfg dedup vs plain batch (5 steps)", rel_l2(a, b), TOL["same_function"])
+    assert rel_l2(a, b) <= TOL["same_function"]
     ref = tiny.oracle.sample(cond, lat0[None].clone(), 5, 5.0)[0]
     assert rel_l2(a, ref) <= TOL["flow_sample"] and rel_l2(b, ref) <= TOL["flow_sample"]
     # a non-uniform "unconditional" context must take the general path (auto-detected) and still match the oracle
