@@ -80,7 +80,9 @@ __device__ __forceinline__ void stage_kv(const uint16_t* __restrict__ Kg, const 
     }
 }
 
-template <bool GLDS>
+// ABL: timing-only ablation mask (tools/bench_attn.py; results are garbage for ABL != 0): 1 no exp2, 2 no row max /
+// rescale, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no LDS-DMA in the loop, 32 no per-tile wait + barrier, 64 no V^T reads
+template <bool GLDS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -128,18 +130,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 
     auto tile = [&](auto masked, const int t) {
         const char* cur = smem + (t & 1) * STAGE_B;
-        if (t + 1 < ntiles) stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
+        if (!(ABL & 16) && t + 1 < ntiles)
+            stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
 
         // ---- S^T = K Q^T for the two 32-key blocks
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kb][r] = (ABL & 8) ? (float)(lane + r) * 0.01f : 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + (offK[kb] ^ (ks << 5)));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                if (ABL & 8) asm volatile("" ::"v"(kf));
+                else s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
         // ---- online softmax on the raw scores (scale folded into the exp2 argument);
@@ -157,13 +161,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
                 }
         }
         float mloc = s[0][0];
+        if (!(ABL & 2)) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        }
         // rescale only when some query's running max actually grows (wave-uniform branch; exact, not a threshold)
-        if (__any(mloc > m_run)) {
+        if (!(ABL & 2) && __any(mloc > m_run)) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
             m_run = m_new;
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -mb));
+                const float arg = __builtin_fmaf(s[kb][r], sc, -mb);
+                const float pv = (ABL & 1) ? arg : __builtin_amdgcn_exp2f(arg);
                 s[kb][r] = pv;
                 psum += pv;
             }
@@ -197,13 +204,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     union { bf16x4 h[2]; bf16x8 v; } vf;
-                    vf.h[0] = *reinterpret_cast<const bf16x4*>(cur + TILE_B + (offV[db] ^ (c << 4)));
-                    vf.h[1] = *reinterpret_cast<const bf16x4*>(cur + TILE_B + (offV[db] ^ ((c + 1) << 4)));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+                    if (ABL & 64) {
+                        vf.v = qf[(c + db) & 3];
+                    } else {   // the lane's 8 keys are one 16-byte chunk of the V^T row (vt_key_pos layout)
+                        vf.v = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (offK[db] ^ (c << 4)));
+                    }
+                    if (ABL & 4) asm volatile("" ::"v"(vf.v), "v"(pf.v));
+                    else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
                 }
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(ABL & 32)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
     const bool pad_tail = ntiles * KV_TILE > Lk;
     for (int t = 0; t < ntiles - 1; ++t) tile(std::false_type{}, t);
@@ -417,10 +430,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
                 const int c = 4 * kb + 2 * ks2;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    union { bf16x4 h[2]; bf16x8 v; } vf;
-                    vf.h[0] = *reinterpret_cast<const bf16x4*>(vt + (offV[db] ^ (c << 4)));
-                    vf.h[1] = *reinterpret_cast<const bf16x4*>(vt + (offV[db] ^ ((c + 1) << 4)));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+                    const bf16x8 vfv = *reinterpret_cast<const bf16x8*>(vt + (offK[db] ^ (c << 4)));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfv, pf.v, o[db], 0, 0, 0);
                 }
             }
         if constexpr (decltype(has_next)::value) {
@@ -466,12 +477,253 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Second-generation kernel (default).  Same decomposition (4 waves x 32 queries share 64-key K / V^T tiles; S^T = K Q^T
+// and O^T += V^T P^T on 32x32x16 MFMAs so that one query lives in lanes q and q+32), with the vector work per score
+// cut to what the exponential needs:
+//  * Q arrives pre-multiplied by scale*log2(e) (the QKV epilogue does it in fp32 before rounding), so a score is
+//    already the exp2 argument;
+//  * lagging maximum: the score accumulators START at -m (the running stabiliser, kept as a 16-register block that is
+//    the C operand of the first QK^T MFMA), so p = exp2(s) with no subtraction and no row maximum on the critical path.
+//    The stabiliser only has to be CLOSE to the maximum: after the exponentials the packed bf16 P registers are reduced
+//    with v_pk_max_u16 (P >= 0: integer order = float order) and a wave-uniform branch fires when some p exceeds 2^6.
+//    Only then is the block's true maximum taken, (O, l) rescaled, and the block's P recomputed from the still-live
+//    scores -- before anything of it entered O or l, so an overflowed p (inf) is never used;
+//  * one 32-key score block is live at a time (QK^T -> exp2 -> pack -> PV per block): 16 score registers;
+//  * V^T tiles are read with ds_read_b128: the 8 keys a lane feeds into one PV MFMA are contiguous in the V^T layout
+//    (vt_key_pos in kernels.h: inside every aligned group of 16 keys the two middle 4-key blocks are swapped);
+//  * 1-D grid, work items ordered head-major and cut into 8 contiguous runs, one per XCD (block b runs on XCD b % 8):
+//    an XCD walks the query tiles of one head after the other, so its K / V^T stay in its 4 MiB L2.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float half_max(float x) {   // max over lanes q and q+32
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+constexpr uint32_t P_LIMIT_BF16 = 0x4280u;   // 64.0 as bf16 bits: a larger p triggers the (rare) re-stabilisation
+
+template <bool GLDS>
+__global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    // ---- work item: XCD-aware remap of the 1-D grid, then (head, batch, query tile)
+    int b, hd, qt;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
+        const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + 127) >> 7;
+        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + 127) >> 7 : 0) : ntq0;
+        const int per_head = p.ragged ? ntq0 + ntq1 : ntq0 * p.B;
+        hd = item / per_head;
+        int rem = item - hd * per_head;
+        if (p.ragged) {
+            b = rem >= ntq0 ? 1 : 0;
+            qt = rem - (b ? ntq0 : 0);
+        } else {
+            b = rem / ntq0;
+            qt = rem - b * ntq0;
+        }
+    }
+    const int q = qt * 128 + wid * 32 + ql;
+    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int kvb = p.kv_batch_stride_zero ? 0 : b;
+    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
+    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
+    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)q * 64 + ks * 16 + hh * 8);
+    if (!p.q_prescaled) {   // test entry point with plain Q: fold scale * log2(e) here (a second bf16 rounding)
+        const float sc = p.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { bf16x8 v; uint32_t u[4]; } w;
+            w.v = qf[ks];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w.u[e] = pack_bf16(__uint_as_float(w.u[e] << 16) * sc, __uint_as_float(w.u[e] & 0xFFFF0000u) * sc);
+            qf[ks] = w.v;
+        }
+    }
+
+    f32x16 o[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m_run = 0.f, l_run = 0.f;
+
+    // LDS fragment offsets: tile row = lane & 31 (+ 32 for the second row block), 16-byte chunk hh, swizzled by the row;
+    // chunk 2*ks + hh of a K row (dims) and chunk 2*(2*kb + ks2) + hh of a V^T row (key positions) follow by XOR
+    int off[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int row = rb * 32 + ql;
+        off[rb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);
+    }
+
+    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
+    const int bias_key = p.ragged ? p.bias_key[b] : -1;
+    const float bias_l2 = p.ragged ? p.bias_log2[b] : 0.f;
+    stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, 0, smem, wid, lane, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tile = [&](auto masked, auto first, const int t) {
+        const char* cur = smem + (t & 1) * STAGE_B;
+        if (t + 1 < ntiles) stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            constexpr bool kFirst = decltype(first)::value;
+            const bool first_block = kFirst && kb == 0;
+            // ---- scores of 32 keys (log2 units, already minus the stabiliser unless this is the very first block)
+            f32x16 s;
+            {
+                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cur + off[kb]);
+                if (first_block) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
+                } else {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], negm, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 1; ks < 4; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + (off[kb] ^ (ks << 5)));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+            }
+            if constexpr (decltype(masked)::value) {   // only the last tile holds padded keys / the weighted key
+                const int key_base = t * KV_TILE + kb * 32 + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key_base + (r & 3) + 8 * (r >> 2);
+                    if (key >= Lk) s[r] = -INFINITY;
+                    else if (key == bias_key) s[r] += bias_l2;
+                }
+            }
+            if (first_block) {   // the stabiliser starts as the exact maximum of the first 32 keys
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                m_run = half_max(mx);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
+            }
+            float pe[16];
+            uint32_t pk[8];
+            auto exponentiate = [&]() {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
+            };
+            exponentiate();
+            if (!first_block) {
+                uint32_t pm = pk_max_u16(pk_max_u16(pk_max_u16(pk[0], pk[1]), pk_max_u16(pk[2], pk[3])),
+                                         pk_max_u16(pk_max_u16(pk[4], pk[5]), pk_max_u16(pk[6], pk[7])));
+                pm = (pm >> 16) > (pm & 0xFFFFu) ? (pm >> 16) : (pm & 0xFFFFu);
+                if (__any(pm > P_LIMIT_BF16)) {
+                    // rare: some query's scores outgrew its stabiliser.  s is relative to the old one: the growth is the
+                    // block maximum itself.  Nothing of this block has entered O or l yet.
+                    float mx = s[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                    const float grow = fmaxf(half_max(mx), 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-grow);
+                    m_run += grow;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] = -m_run; s[r] -= grow; }
+                    exponentiate();
+                }
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { ps0 += pe[r]; ps1 += pe[r + 1]; }
+            l_run += ps0 + ps1;
+            // ---- O^T += V^T P^T for these 32 keys: the lane's 8 keys of each 16-key group are one 16-byte chunk of V^T
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pk[4 * ks2 + e];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const bool pad_tail = ntiles * KV_TILE > Lk;
+    if (ntiles == 1) {
+        if (pad_tail) tile(std::true_type{}, std::true_type{}, 0);
+        else tile(std::false_type{}, std::true_type{}, 0);
+    } else {
+        tile(std::false_type{}, std::true_type{}, 0);
+        for (int t = 1; t < ntiles - 1; ++t) tile(std::false_type{}, std::false_type{}, t);
+        if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1);
+        else tile(std::false_type{}, std::false_type{}, ntiles - 1);
+    }
+
+    const float inv = 1.0f / half_sum(l_run);
+    {
+        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
+        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        uint16_t* dst = p.O + orow + hd * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                // lane (q, hh) holds dims db*32 + 8g + 4hh + {0..3}; the two lanes of a query swap halves so that each
+                // writes 8 consecutive dims (16-byte stores)
+                uint2 even, odd;
+                even.x = pack_bf16(o[db][8 * gp] * inv, o[db][8 * gp + 1] * inv);
+                even.y = pack_bf16(o[db][8 * gp + 2] * inv, o[db][8 * gp + 3] * inv);
+                odd.x = pack_bf16(o[db][8 * gp + 4] * inv, o[db][8 * gp + 5] * inv);
+                odd.y = pack_bf16(o[db][8 * gp + 6] * inv, o[db][8 * gp + 7] * inv);
+                // permlane32_swap(vdst = even, src = odd): lanes 32-63 of `even` <-> lanes 0-31 of `odd`
+                const u32x2 rx = __builtin_amdgcn_permlane32_swap(even.x, odd.x, false, false);
+                const u32x2 ry = __builtin_amdgcn_permlane32_swap(even.y, odd.y, false, false);
+                // lower lanes: rx[0] = own even, rx[1] = upper's even  -> dims 8g..8g+7   (g = 2gp)
+                // upper lanes: rx[0] = lower's odd, rx[1] = own odd    -> dims 8(g+1)..8(g+1)+7
+                uint4 out;
+                out.x = rx[0]; out.y = ry[0]; out.z = rx[1]; out.w = ry[1];
+                if (q < Lq) *reinterpret_cast<uint4*>(dst + db * 32 + 16 * gp + 8 * hh) = out;
+            }
+    }
+}
+
 }  // namespace
 
 static bool g_attn_glds = true;
 static bool g_attn_pipelined = false;  // measured slower than the plain kernel (2 vs 3 waves/SIMD): profiles/r01_attention_variants.md
+static int g_attn_ablate = 0;
+void attn_set_ablate(int mask) { g_attn_ablate = mask; }
 void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
+
+static int g_attn_gen = 2;
+void attn_set_generation(int gen) { if (gen == 1 || gen == 2) g_attn_gen = gen; }
+float attn_q_scale(float scale) { return g_attn_gen == 2 ? scale * 1.4426950408889634f : 1.0f; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.ragged) {
@@ -491,10 +743,28 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         for (int b = 0; b < p.B; ++b) pairs += (double)p.lq_b[b] * p.lk_b[b];
     }
     ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
+    if (g_attn_gen == 2 && !g_attn_ablate && !g_attn_pipelined) {
+        int items = 0;
+        if (p.ragged) for (int b = 0; b < p.B; ++b) items += (p.lq_b[b] + 127) / 128;
+        else items = ((p.Lq + 127) / 128) * p.B;
+        items *= p.H;
+        if (g_attn_glds) hipLaunchKernelGGL(attn2_kernel<true>, dim3(items), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(attn2_kernel<false>, dim3(items), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    if (p.q_prescaled) return hipErrorInvalidValue;   // the first-generation kernels scale the scores themselves
     dim3 grid(p.Lq_pad / 128, p.H, p.B);
     if (g_attn_pipelined) {
         if (g_attn_glds) hipLaunchKernelGGL(attn_kernel_sp<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(attn_kernel_sp<false>, grid, dim3(256), 0, s, p);
+    } else if (g_attn_glds && g_attn_ablate) {
+        switch (g_attn_ablate) {
+#define R3G_ABL(m) case m: hipLaunchKernelGGL((attn_kernel<true, m>), grid, dim3(256), 0, s, p); break;
+            R3G_ABL(1) R3G_ABL(2) R3G_ABL(3) R3G_ABL(4) R3G_ABL(8) R3G_ABL(12) R3G_ABL(16) R3G_ABL(48) R3G_ABL(64) R3G_ABL(68)
+            R3G_ABL(15) R3G_ABL(63) R3G_ABL(127)
+#undef R3G_ABL
+            default: return hipErrorInvalidValue;
+        }
     } else if (g_attn_glds) {
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, p);
     } else {

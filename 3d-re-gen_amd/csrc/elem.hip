@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
                 const float r = rsqrtf(wave_sum(dlt * dlt) * (1.f / 64.f) + p.eps);
                 q = dlt * r * qw + qb;
             }
+            if (p.q_scale != 0.f) q *= p.q_scale;
             if (valid) p.Q[(((int64_t)b * p.H + h) * p.Lq_pad + drow) * 64 + lane] = f2bf(q);
         }
         if (p.k_off >= 0 && p.K) {
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
         // each wave writes 16 d-rows of 64 tokens (128 B per row); pad tokens are written as zeros
         for (int i = 0; i < 16; ++i) {
             const int d = wid * 16 + i;
-            const int64_t col = (int64_t)p.dst_row0 + tok0 + lane;
-            if (col < p.Lk_pad) p.Vt[(((int64_t)b * p.H + h) * 64 + d) * (int64_t)p.Lk_pad + col] = vt[d][lane];
+            const int64_t col = (int64_t)p.dst_row0 + tok0 + lane;   // 64-aligned run of keys: vt_key_pos stays inside it
+            if (col < p.Lk_pad) p.Vt[(((int64_t)b * p.H + h) * 64 + d) * (int64_t)p.Lk_pad + vt_key_pos(col)] = vt[d][lane];
         }
     }
 }

@@ -151,6 +151,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     v[j] = (v[j] - mean) * r * w + b;
                 }
             }
+            if (type == 0 && e.q_scale != 0.f) {   // softmax scale * log2(e) folded into q before the bf16 rounding
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= e.q_scale;
+            }
             if (lds_wave != nullptr) {
                 // stage the normalised tile in the wave's LDS scratch: Q / K as [token][64 dims] (16-byte chunks
                 // swizzled by the token), V as [dim][token] (chunks of 8 tokens swizzled by the dim group)
@@ -202,8 +206,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     *reinterpret_cast<uint2*>(base + j * 16 + dbase) = pk;
                 }
             } else {
-                // V^T[d][token]: 16 consecutive tokens (lane&15) per d -> 32-byte segments
-                uint16_t* base = e.Vt + (((int64_t)ob * e.heads + head) * 64) * (int64_t)e.Lk_pad + drow;
+                // V^T[d][key position]: one token per lane (2-byte stores; the LDS-transposed path below is the fast one)
+                uint16_t* base = e.Vt + (((int64_t)ob * e.heads + head) * 64) * (int64_t)e.Lk_pad + vt_key_pos(drow);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -246,30 +250,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     *reinterpret_cast<uint4*>(base + cc * 8) = dv;
                 }
             } else {
-                // V^T[dim][token]: a lane takes 8 consecutive tokens of one dim (16 bytes) when they stay together in
-                // the destination, otherwise token by token (segment boundaries, the ragged end of the rows)
-                constexpr int CPR = WROWS / 8;   // 16-byte chunks per dim row
+                // V^T[dim][key position]: a lane takes the 8 tokens that are contiguous in the destination (vt_key_pos:
+                // tokens 16u + 4h + {0..3} and 16u + 8 + 4h + {0..3} = positions 16u + 8h + {0..7}, 16 bytes) when the
+                // whole 16-token group stays together there, otherwise token by token (segment boundaries, ragged ends)
+                constexpr int CPR = WROWS / 8;   // 16-byte chunks per dim row of the LDS image
 #pragma unroll
                 for (int t = 0; t < 64 / (64 / CPR); ++t) {
                     const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
-                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + d * (WROWS * 2) +
-                                                                     ((ck ^ ((d >> 2) & (CPR - 1))) << 4));
-                    const int mfirst = mw + ck * 8;
-                    int ob0, ob7;
-                    int64_t dr0, dr7;
-                    const bool ok0 = map_row(mfirst, ob0, dr0), ok7 = map_row(mfirst + 7, ob7, dr7);
+                    const int u = ck >> 1, h8 = (ck & 1) * 8;
+                    const int sw = (d >> 2) & (CPR - 1);
+                    const char* drow_lds = lds_wave + d * (WROWS * 2);
+                    const uint2 lo = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u) ^ sw) << 4) + h8);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
+                    const int mfirst = mw + 16 * u;
+                    int ob0, ob15;
+                    int64_t dr0, dr15;
+                    const bool ok0 = map_row(mfirst, ob0, dr0), ok15 = map_row(mfirst + 15, ob15, dr15);
                     const int64_t lk = e.Lk_pad;
-                    if (ok0 && ok7 && ob0 == ob7 && dr7 == dr0 + 7 && ((dr0 | lk) & 7) == 0) {
-                        uint16_t* dst = e.Vt + (((int64_t)ob0 * e.heads + head) * 64 + d) * lk + dr0;
-                        *reinterpret_cast<uint4*>(dst) = dv;
+                    if (ok0 && ok15 && ob0 == ob15 && dr15 == dr0 + 15 && ((dr0 & 15) | (lk & 7)) == 0) {
+                        uint16_t* dst = e.Vt + (((int64_t)ob0 * e.heads + head) * 64 + d) * lk + dr0 + h8;
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                     } else {
-                        const uint16_t* h = reinterpret_cast<const uint16_t*>(&dv);
+                        const uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
+                            const int tk = 16 * u + (k < 4 ? (h8 >> 1) + k : 8 + (h8 >> 1) + (k - 4));
                             int ob;
                             int64_t dr;
-                            if (map_row(mfirst + k, ob, dr))
-                                e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + dr] = h[k];
+                            if (map_row(mw + tk, ob, dr))
+                                e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + vt_key_pos(dr)] =
+                                    (uint16_t)(w4[k >> 1] >> ((k & 1) * 16));
                         }
                     }
                 }
@@ -914,6 +924,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 1, g_num_cu = 256;
+bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
 
 template <int EPI>
@@ -935,12 +946,13 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             // the 256x256 tile needs half the bytes per flop of the 128x128 one and wins wherever its coarser grid
             // still fills the machine; otherwise 128x128 with 8 waves (4 per SIMD at two workgroups per CU).
             if ((p2.M == 0 || p2.N % 256 == 0) && p.N % 256 == 0 && t256 >= 128 &&
-                (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills))) waves = 9;
+                (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills)))
+                waves = g_gemm_phased ? 11 : 9;   // phased 256x256 kernel (falls back to 8 waves when K % 128 != 0)
             else waves = 8;
         }
     }
     if (waves == 11 && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) return launch_gemm8<EPI>(p, p2, s);   // phased 256x256x64
-    if (waves == 11) waves = 8;
+    if (waves == 11) waves = g_gemm_waves == 0 ? 9 : 8;
     if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, p2, glds, s);
     if (waves == 9) return launch_cfg<EPI, 8, 1>(p, p2, glds, s);   // 256x256 tile, 8 waves of 128x64
@@ -959,6 +971,7 @@ void gemm_set_auto_rule(int rule, int num_cu) {
     if (num_cu > 0) g_num_cu = num_cu;
 }
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
+void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_config(int waves, int stages) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;

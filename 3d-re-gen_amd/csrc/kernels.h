@@ -25,6 +25,14 @@ enum QkvLayout {
     QKV_Q_ONLY = 3,    // q heads only                                          (geo decoder c_q)
 };
 
+// Position of key k inside a V^T row.  Within every aligned group of 16 keys the two middle 4-key blocks are swapped
+// (key 8g + 4h + e sits at 8h + 4g + e), so that the 8 keys one lane feeds into a PV MFMA -- {4h..4h+3} and
+// {8+4h..8+4h+3} of the group, the keys its S^T accumulator registers hold -- are one contiguous 16-byte chunk.
+__host__ __device__ inline int64_t vt_key_pos(int64_t k) {
+    const int64_t p = k & 15;
+    return (k & ~(int64_t)15) | (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1);
+}
+
 // destination of the EPI_QKV epilogue (what qkv_split_kernel produces, fused into the projection)
 struct QkvEpi {
     uint16_t* Q; uint16_t* K; uint16_t* Vt;
@@ -33,6 +41,7 @@ struct QkvEpi {
     int heads, layout, norm;  // QkvLayout, QkNorm
     const float *qw, *qb, *kw, *kb;
     float eps;
+    float q_scale;        // q is multiplied by this (in fp32, before rounding to bf16); 0 means 1
     // optional row segments (nseg > 0): GEMM row m in [seg_m0, seg_m1) goes to attention batch seg_batch, destination
     // row seg_dst + (m - seg_m0); rows in no segment are dropped.  nseg == 0: batch = GEMM batch, row = dst_row0 + m.
     int nseg;
@@ -62,10 +71,12 @@ hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
 hipError_t gemm_launch2(const GemmArgs& p, int batch, const GemmArgs* p2, int batch2, hipStream_t s);
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
+void attn_set_ablate(int mask);   // timing-only ablation builds of the attention kernel (tools/bench_attn.py)
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
 void gemm_set_config(int waves, int stages);
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
+void gemm_set_phased(bool on);   // 256x256 tiles: phased kernel (default) or the two-stage one
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
@@ -80,6 +91,7 @@ struct AttnArgs {
     int Lk, Lk_pad;      // valid / allocated keys (Lk_pad % 64 == 0)
     int kv_batch_stride_zero;  // 1: K/V are shared by all batches (cross attention with B query chunks)
     float scale;         // softmax scale (1/sqrt(64))
+    int q_prescaled;     // 1: Q already holds q * scale * log2(e) (QkvEpi::q_scale = attn_q_scale())
     // Ragged mode (B <= 2; CFG with a de-duplicated unconditional context): per-batch lengths, an output row map
     //   row(b, q) = q < o_split[b] ? o_row0[b] + q : o_row_split[b] + (q - o_split[b])     (strideO ignored)
     // and one key per batch that stands for `2^bias_log2[b]` identical keys (its score gets +bias_log2 in log2 units;
@@ -93,6 +105,9 @@ struct AttnArgs {
 };
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
+// factor the producers of Q fold into it for the current attention kernel: scale * log2(e) (generation 2), or 1
+float attn_q_scale(float scale);
+void attn_set_generation(int gen);   // 2 (default) | 1: the first-round kernel (expects plain Q; same V^T layout)
 
 // ------------------------------------------------------------------ elementwise / norms (elem.hip)
 // y(bf16)[r][c] = ((x - mean) * rstd * (w ? w[c] : 1) + (b ? b[c] : 0)) * (1 + scale[batch][c]) + shift[batch][c]
@@ -123,6 +138,7 @@ struct QkvSplitArgs {
     int norm;                  // QkNorm
     const float* qw; const float* qb; const float* kw; const float* kb;  // [64] scale / bias
     float eps;
+    float q_scale;             // as QkvEpi::q_scale
 };
 hipError_t qkv_split_launch(const QkvSplitArgs& p, hipStream_t s);
 

@@ -182,6 +182,7 @@ static int gemm_qkv(Model& m, const uint16_t* A, int64_t lda, int64_t strideA, c
         p.qkv.Q = q.Q; p.qkv.K = q.K; p.qkv.Vt = q.Vt; p.qkv.Lq_pad = q.Lq_pad; p.qkv.Lk_pad = q.Lk_pad;
         p.qkv.dst_row0 = q.dst_row0; p.qkv.heads = q.H; p.qkv.layout = layout; p.qkv.norm = q.norm;
         p.qkv.qw = q.qw; p.qkv.qb = q.qb; p.qkv.kw = q.kw; p.qkv.kb = q.kb; p.qkv.eps = q.eps;
+        p.qkv.q_scale = q.q_scale;
         hipError_t e = gemm_launch(p, batch, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv)");
         return R3G_OK;
@@ -214,6 +215,7 @@ static int attention(const Model& m, int B, int heads, int Lq, int Lq_pad, int L
     p.B = B; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
     p.kv_batch_stride_zero = shared_kv ? 1 : 0;
     p.scale = 0.125f;
+    p.q_prescaled = attn_q_scale(0.125f) != 1.0f;
     hipError_t e = attention_launch(p, s);
     if (e != hipSuccess) return hip_fail(e, "attention_launch");
     return R3G_OK;
@@ -308,7 +310,7 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
             q.src = m.qkv + (int64_t)row0 * qkvld; q.ld = qkvld; q.src_batch_stride = qkvs;
             q.q_off = 0; q.k_off = H; q.v_off = 2 * H; q.head_stride = 64;
             q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Tpad; q.Lk_pad = Tpad; q.dst_row0 = row0;
-            q.B = B; q.H = heads; q.L = rows; q.norm = QKN_RMS; q.eps = 1e-6f;
+            q.B = B; q.H = heads; q.L = rows; q.norm = QKN_RMS; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
             R3G_RC(get_vec(m, blk + "_attn.norm.query_norm.scale", 64, &q.qw));
             R3G_RC(get_vec(m, blk + "_attn.norm.key_norm.scale", 64, &q.kw));
             R3G_RC(gemm_qkv(m, m.xn + (int64_t)row0 * H, H, xs, l, 0, 3 * H, rows, H, B, q, QKV_KHD, s));
@@ -346,7 +348,7 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
         q.src = m.qkv; q.ld = qkvld; q.src_batch_stride = qkvs;
         q.q_off = 0; q.k_off = H; q.v_off = 2 * H; q.head_stride = 64;
         q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Tpad; q.Lk_pad = Tpad; q.dst_row0 = 0;
-        q.B = B; q.H = heads; q.L = T; q.norm = QKN_RMS; q.eps = 1e-6f;
+        q.B = B; q.H = heads; q.L = T; q.norm = QKN_RMS; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
         R3G_RC(get_vec(m, blk + ".norm.query_norm.scale", 64, &q.qw));
         R3G_RC(get_vec(m, blk + ".norm.key_norm.scale", 64, &q.kw));
         R3G_RC(gemm_qkv(m, m.xn, H, xs, l, 0, 3 * H, T, H, B, q, QKV_KHD, s));
@@ -409,6 +411,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
     AttnArgs at{};
     at.Q = m.Q; at.K = m.K; at.Vt = m.Vt; at.O = m.cat; at.ldo = catld; at.strideO = 0;
     at.B = 2; at.H = heads; at.Lq = T; at.Lq_pad = Tpad; at.Lk = T; at.Lk_pad = Tpad; at.scale = 0.125f;
+    at.q_prescaled = attn_q_scale(0.125f) != 1.0f;
     at.ragged = 1;
     at.lq_b[0] = T; at.lk_b[0] = T; at.lq_b[1] = Nl + 1; at.lk_b[1] = Nl + 1;
     at.o_row0[0] = 0; at.o_split[0] = T; at.o_row_split[0] = 0;
@@ -420,7 +423,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         *q = QkvSplitArgs{};
         q->q_off = 0; q->k_off = H; q->v_off = 2 * H; q->head_stride = 64;
         q->Q = m.Q; q->K = m.K; q->Vt = m.Vt; q->Lq_pad = Tpad; q->Lk_pad = Tpad;
-        q->H = heads; q->norm = QKN_RMS; q->eps = 1e-6f;
+        q->H = heads; q->norm = QKN_RMS; q->eps = 1e-6f; q->q_scale = attn_q_scale(0.125f);
         R3G_RC(get_vec(m, qn, 64, &q->qw));
         R3G_RC(get_vec(m, kn, 64, &q->kw));
         return R3G_OK;
@@ -432,7 +435,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         p.M = M; p.N = 3 * H; p.K = H; p.epi = EPI_QKV;
         p.qkv.Q = q.Q; p.qkv.K = q.K; p.qkv.Vt = q.Vt; p.qkv.Lq_pad = q.Lq_pad; p.qkv.Lk_pad = q.Lk_pad;
         p.qkv.dst_row0 = 0; p.qkv.heads = heads; p.qkv.layout = QKV_KHD; p.qkv.norm = q.norm;
-        p.qkv.qw = q.qw; p.qkv.kw = q.kw; p.qkv.eps = q.eps; p.qkv.nseg = nseg;
+        p.qkv.qw = q.qw; p.qkv.kw = q.kw; p.qkv.eps = q.eps; p.qkv.q_scale = q.q_scale; p.qkv.nseg = nseg;
         for (int i = 0; i < nseg; ++i) {
             p.qkv.seg_m0[i] = seg[i][0]; p.qkv.seg_m1[i] = seg[i][1]; p.qkv.seg_batch[i] = seg[i][2]; p.qkv.seg_dst[i] = seg[i][3];
         }
@@ -567,7 +570,7 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
         q.src = m.qkv; q.ld = 3 * W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = 64; q.v_off = 128; q.head_stride = 192;  // per-head interleaved (q,k,v)
         q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = (int)rup(Nl, 128); q.Lk_pad = (int)rup(Nl, 128); q.dst_row0 = 0;
-        q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f;
+        q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
         q.norm = c.vae_qk_norm ? QKN_LAYERNORM : QKN_NONE;
         if (c.vae_qk_norm) {
             R3G_RC(get_vec(m, blk + ".attn.attention.q_norm.weight", 64, &q.qw));
@@ -597,7 +600,7 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
     q.src = m.qkv; q.ld = 2 * W; q.src_batch_stride = 0;
     q.q_off = -1; q.k_off = 0; q.v_off = 64; q.head_stride = 128;  // per-head interleaved (k,v)
     q.Q = nullptr; q.K = m.geoK; q.Vt = m.geoVt; q.Lq_pad = 0; q.Lk_pad = (int)rup(Nl, 64); q.dst_row0 = 0;
-    q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f;
+    q.B = 1; q.H = heads; q.L = Nl; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
     const bool qkn = c.vae_qk_norm && c.vae_ln_post;
     q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
     if (qkn) {
@@ -647,7 +650,7 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
         q.Q = m.Q; q.K = nullptr; q.Vt = nullptr; q.Lq_pad = npad; q.Lk_pad = 0; q.dst_row0 = 0;
-        q.B = 1; q.H = heads; q.L = n; q.eps = 1e-6f;
+        q.B = 1; q.H = heads; q.L = n; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
         q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
         if (qkn) {
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
@@ -689,7 +692,7 @@ static int cond_encode(Model& m, const float* img, uint16_t* out, hipStream_t s)
         q.src = m.qkv; q.ld = 3 * Hc; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = Hc; q.v_off = 2 * Hc; q.head_stride = 64;
         q.Q = m.Q; q.K = m.K; q.Vt = m.Vt; q.Lq_pad = Lp; q.Lk_pad = Lp; q.dst_row0 = 0;
-        q.B = 1; q.H = heads; q.L = L; q.norm = QKN_NONE; q.eps = 0.f;
+        q.B = 1; q.H = heads; q.L = L; q.norm = QKN_NONE; q.eps = 0.f; q.q_scale = attn_q_scale(0.125f);
         R3G_RC(gemm_qkv(m, m.xn, Hc, 0, l, 0, 3 * Hc, L, Hc, 1, q, QKV_KHD, s));
         R3G_RC(attention(m, 1, heads, L, Lp, L, Lp, m.cat, Hc, 0, m.K, m.Vt, false, s));
         R3G_RC(get_lin(m, blk + ".attention.output.dense", true, &l));
@@ -947,7 +950,10 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);
     else if (!strcmp(name, "gemm_auto_rule")) gemm_set_auto_rule(value, 0);
     else if (!strcmp(name, "gemm_wide_epilogue")) gemm_set_wide_epilogue(value != 0);
+    else if (!strcmp(name, "gemm_phased")) gemm_set_phased(value != 0);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
+    else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
+    else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
     else if (!strcmp(name, "mc_rows")) mc_set_rows_per_wave(value);
     else if (!strcmp(name, "lds_dma")) { gemm_set_glds(value != 0); attn_set_glds(value != 0); }
     else return fail(R3G_ERR_INVALID, "r3g_set_option: unknown option '%s'", name);

@@ -10,7 +10,10 @@ folder is created and emptied; one `<out>/<stem>/<stem>.glb` per image; FileNotF
 What differs, by design (MI355X-first):
   * one persistent process per GPU (torch.distributed over RCCL; the reference spawns one process per IMAGE and
     reloads both pipelines each time, :119-130) -- the model is loaded once per rank;
-  * crops are taken round-robin from the SORTED file list (the reference's os.listdir order is filesystem dependent);
+  * with more than one GPU, rank 0 decodes the crops and broadcasts the packed batch over RCCL, ranks claim object
+    indices dynamically from a shared counter (no static i % num_devices split, reference :188-191), and the cleaned
+    meshes are gathered to rank 0, which writes the GLBs (r3g/dist.py); files are the SORTED list (the reference's
+    os.listdir order is filesystem dependent); the result is byte-identical to the one-process run;
   * per-object failures are collected into a status list and printed (the reference's pool path swallows them,
     :135-136); the exit code follows the reference: 0 when the stage ran, non-zero only on setup errors
     (no images / no weights), or when the sequential path hits an exception (as in the reference, :212-213);
@@ -118,14 +121,10 @@ def clean_and_validate_mesh(mesh, min_faces=10, target_face_count=None):
     return mesh
 
 
-def process_image(image_path, shapegen, texgen, cleaners, output_dir, config):
-    """reference process_image :67-105"""
+def generate_mesh(image, base, shapegen, texgen, cleaners, config):
+    """reference process_image :69-97 without the file I/O around it: RGBA image -> cleaned (and textured) mesh"""
     import torch
-    from PIL import Image
-    image = Image.open(image_path).convert("RGBA")
-    base = os.path.splitext(os.path.basename(image_path))[0]
     print("Processing %s..." % base)
-    t0 = time.time()
     mesh = shapegen(image=image, num_inference_steps=config.get("num_inf_steps_hy", 100),
                     octree_resolution=config.get("octree_resolution_hy", 380), num_chunks=config.get("num_chunks_hy", 20000),
                     generator=torch.manual_seed(config.get("seed", 12345)), output_type="trimesh")[0]
@@ -137,22 +136,38 @@ def process_image(image_path, shapegen, texgen, cleaners, output_dir, config):
     for cleaner in cleaners:
         mesh = cleaner(mesh)
     print("Cleaned mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
-    mesh = texgen(mesh, image=image)
+    return texgen(mesh, image=image)
+
+
+def export_mesh(mesh, base, output_dir):
+    """reference :99-102: <out>/<stem>/<stem>.glb"""
     out_dir = os.path.join(output_dir, base)
     os.makedirs(out_dir, exist_ok=True)
     out_path = os.path.join(out_dir, base + ".glb")
     mesh.export(out_path)
+    return out_path
+
+
+def process_image(image_path, shapegen, texgen, cleaners, output_dir, config):
+    """reference process_image :67-105"""
+    from PIL import Image
+    image = Image.open(image_path).convert("RGBA")
+    base = os.path.splitext(os.path.basename(image_path))[0]
+    t0 = time.time()
+    mesh = generate_mesh(image, base, shapegen, texgen, cleaners, config)
+    out_path = export_mesh(mesh, base, output_dir)
     print("Saved %s to %s in %.2f seconds." % (base, out_path, time.time() - t0))
     return out_path
 
 
 def partition(n_items, rank, world):
-    """static round-robin over the sorted list (reference: i % num_devices, :188-191)"""
+    """static round-robin over the sorted list (reference: i % num_devices, :188-191); the distributed path hands
+    indices out dynamically instead (r3g.dist.WorkQueue) -- kept for tools that want a fixed split"""
     return list(range(rank, n_items, world))
 
 
 def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_errors):
-    """One persistent rank: load the model once, process its share, return [(index, path, status, seconds)]."""
+    """Sequential path (one process): load the model once, process every image, return [(index, path, status, seconds)]."""
     import torch
     device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu"
     shapegen, texgen, cleaners = factory(config, device)
@@ -167,7 +182,61 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
                 raise
             print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
             results.append((i, image_paths[i], "error: %s" % e, time.time() - t0))
-    return results
+    return results, getattr(texgen, "implemented", True)
+
+
+def run_distributed(config, input_folder, output_folder, rank, world, factory):
+    """One persistent rank per GPU.  Rank 0 decodes the crops and broadcasts the packed batch (RCCL: into every rank's
+    HBM); ranks claim object indices from a shared counter as they become free, keep their meshes, and rank 0 gathers
+    and writes them.  Returns (results, textured) on rank 0, (None, None) elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from PIL import Image
+    from r3g import dist as rdist
+    from r3g.mesh import Mesh
+    device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu"
+    names = [None]
+    crops = None
+    if rank == 0:
+        image_paths = list_images(input_folder)
+        names = [image_paths]
+        crops = [np.asarray(Image.open(p).convert("RGBA")) for p in image_paths]
+    dist.broadcast_object_list(names, src=0)          # the file names only (the pixels travel as tensors below)
+    image_paths = names[0]
+    crops = rdist.broadcast_crops(crops, src=0)
+    queue = rdist.WorkQueue(len(image_paths), name="r3g_stage_objects")
+    shapegen, texgen, cleaners = factory(config, device)
+    mine, status = [], []
+    while True:
+        i = queue.claim()
+        if i is None:
+            break
+        base = os.path.splitext(os.path.basename(image_paths[i]))[0]
+        t0 = time.time()
+        try:
+            image = Image.fromarray(crops[i].cpu().numpy(), "RGBA")
+            mesh = generate_mesh(image, base, shapegen, texgen, cleaners, config)
+            mine.append((i, mesh))
+            status.append((i, image_paths[i], "ok", time.time() - t0, rank))
+        except Exception as e:      # one object failing must not fail the stage (reference :135-136 swallows it silently)
+            print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
+            status.append((i, image_paths[i], "error: %s" % e, time.time() - t0, rank))
+    local = []
+    for i, mesh in mine:
+        if getattr(mesh, "_dv", None) is not None:
+            local.append((i, mesh._dv, mesh._df))          # still in HBM: goes over RCCL from there
+        else:
+            local.append((i, np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32)))
+    gathered = rdist.gather_meshes(local, dst=0)
+    all_status = [None] * world
+    dist.all_gather_object(all_status, status)
+    if rank != 0:
+        return None, None
+    for i in sorted(gathered):
+        v, f = gathered[i]
+        export_mesh(Mesh(v, f), os.path.splitext(os.path.basename(image_paths[i]))[0], output_folder)
+    return sorted(r for part in all_status for r in part), getattr(texgen, "implemented", True)
 
 
 def main(argv=None, factory=default_factory):
@@ -199,38 +268,54 @@ def main(argv=None, factory=default_factory):
                    os.path.abspath(__file__), "--config", args.config]
             return subprocess.run(cmd, env=env, check=True).returncode
         print("Running sequentially (%s)." % ("no GPU found" if n_dev == 0 else "only 1 slot or only 1 image"))
-        results = run_rank(config, image_paths, output_folder, 0, 1, factory, swallow_errors=False)
-        report(results)
-        return 0
+        results, textured = run_rank(config, image_paths, output_folder, 0, 1, factory, swallow_errors=False)
+        return finish(report(results, textured), config)
 
-    # ---- distributed: rank 0 prepares the output folder, everybody waits, then object-parallel work
+    # ---- distributed: rank 0 prepares the output folder and scatters the crops, everybody works, rank 0 gathers
     import torch.distributed as dist
     backend = "nccl" if torch.cuda.is_available() else "gloo"
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend)
+    rc = 0
     try:
         if rank == 0 and not os.environ.get("R3G_STAGE_PREPARED"):
             os.makedirs(output_folder, exist_ok=True)
             clear_output_directory(output_folder)
         dist.barrier()
-        image_paths = list_images(input_folder)
-        mine = run_rank(config, image_paths, output_folder, rank, world, factory, swallow_errors=True)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)   # tiny status list; the meshes themselves went to the filesystem
+        results, textured = run_distributed(config, input_folder, output_folder, rank, world, factory)
         if rank == 0:
-            report(sorted(r for part in gathered for r in part))
+            rc = finish(report(results, textured), config)
             print("All parallel tasks completed.")
     finally:
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
-def report(results):
+def report(results, textured=True):
     ok = sum(1 for r in results if r[2] == "ok")
-    print(json.dumps({"stage": "Hunyuan_2d_to_3d", "objects": len(results), "ok": ok,
-                      "failed": [os.path.basename(r[1]) for r in results if r[2] != "ok"],
-                      "seconds": [round(r[3], 3) for r in results]}))
+    rep = {"stage": "Hunyuan_2d_to_3d", "objects": len(results), "ok": ok,
+           "failed": [os.path.basename(r[1]) for r in results if r[2] != "ok"],
+           "seconds": [round(r[3], 3) for r in results],
+           "textured": bool(textured)}
+    if results and len(results[0]) > 4:
+        rep["rank_of_object"] = [r[4] for r in results]
+    print(json.dumps(rep))
+    return rep
+
+
+def finish(rep, config):
+    """exit code of the stage.  The texture stage (hy3dgen.texgen) is not implemented on this path yet: the GLBs carry
+    geometry only.  That is reported (`"textured": false`) and warned about; `r3g_require_textures: true` in the config
+    turns it into a failure so that a pipeline that needs base-colour textures does not silently run on without them."""
+    if not rep["textured"]:
+        msg = ("[r3g] WARNING: the texture stage is not implemented on the MI355X path: %d GLB(s) written WITHOUT "
+               "baseColorTexture (geometry only)" % rep["ok"])
+        print(msg, file=sys.stderr)
+        if config.get("r3g_require_textures", False):
+            print("[r3g] r3g_require_textures is set: failing the stage", file=sys.stderr)
+            return 3
+    return 0
 
 
 if __name__ == "__main__":

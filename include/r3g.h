@@ -168,8 +168,10 @@ int r3g_grid_query(r3g_ctx* ctx, double bound, int octree_resolution, float* d_g
  * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
 int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, void* d_c,
                 int64_t ldc, const float* d_gate, int m, int n, int k, int epilogue, int use_lds_dma, void* stream);
-/* softmax(Q K^T / 8) V for head_dim 64: Q bf16 [B][H][lq_pad][64], K bf16 [B][H][lk_pad][64],
- * Vt bf16 [B][H][64][lk_pad] -> O bf16 [B][lq][H*64]. */
+/* softmax(Q K^T / 8) V for head_dim 64: Q bf16 [B][H][lq_pad][64] (plain q: this entry point folds the softmax scale
+ * in itself), K bf16 [B][H][lk_pad][64], Vt bf16 [B][H][64][lk_pad] -> O bf16 [B][lq][H*64].
+ * Vt holds V transposed with the keys of each row in the kernel's operand order: inside every aligned group of 16 keys
+ * the two middle 4-key blocks are swapped (key 8g+4h+e at position 8h+4g+e; python: r3g.layout.make_vt). */
 int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
                      int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream);
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).  Families, in order:
@@ -185,7 +187,8 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
  * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 tile | 10 = 256x128 | 16 | 32 = deep ring), "gemm_raster"
- * (-1 auto | tile columns per rasterisation group), "attn_pipelined" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per
+ * (-1 auto | tile columns per rasterisation group), "gemm_phased" (1: 256x256 tiles on the phased counted-vmcnt kernel),
+ * "attn_generation" (2 | 1 = the first-round kernel), "attn_pipelined" (0), "attn_ablate" (timing-only masks), "mc_rows" (4 | 8 | 16 | 32 node rows per
  * wave in the marching-cubes row kernel).  None of them changes a result bit, except fuse_qkv / batch_mods / cfg_dedup
  * (different summation order, same function). */
 int r3g_set_option(const char* name, int value);

@@ -98,12 +98,12 @@ def _attn_case(torch, B, H, Lq, Lk, shared, seed):
     lqp, lkp = (Lq + 127) // 128 * 128, (Lk + 63) // 64 * 64
     Q = torch.full((B, H, lqp, 64), 3.0, device="cuda", dtype=torch.bfloat16)
     K = torch.full((Bk, H, lkp, 64), 7.0, device="cuda", dtype=torch.bfloat16)     # junk in the padded keys
-    Vt = torch.zeros((Bk, H, 64, lkp), device="cuda", dtype=torch.bfloat16)
+    from r3g.layout import make_vt
+    Vt = make_vt(v, lkp)          # V^T in the kernel's key order (kernels.h vt_key_pos); padded keys zero
     Q[:, :, :Lq] = q.to(torch.bfloat16)
     K[:, :, :Lk] = k.to(torch.bfloat16)
-    Vt[:, :, :, :Lk] = v.to(torch.bfloat16).transpose(2, 3)
     ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float().expand(B, -1, -1, -1),
-                                                           Vt[:, :, :, :Lk].float().transpose(2, 3).expand(B, -1, -1, -1))
+                                                           v.to(torch.bfloat16).float().expand(B, -1, -1, -1))
     ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, H * 64)
     return Q, K, Vt, ref, lqp, lkp
 
@@ -127,15 +127,16 @@ def test_attention_forced_rescale(env):
     torch, L, ffi = env
     B, H, Lq, Lk = 1, 1, 128, 512
     Q, K, Vt, _, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, 0, 11)
+    from r3g.layout import read_vt
     K[0, 0, 400] = (Q[0, 0, 5].float() * 4).to(torch.bfloat16)
-    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float(),
-                                                           Vt[:, :, :, :Lk].float().transpose(2, 3))
+    vrows = read_vt(Vt, Lk).float()
+    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float(), vrows)
     ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, 64)
     o = torch.zeros(B, Lq, 64, device="cuda", dtype=torch.bfloat16)
     ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, 0, 1,
                                  stream(torch)))
     assert rel_l2(o.float(), ref) <= 1e-2
-    assert torch.allclose(o.float()[0, 5], Vt[0, 0, :, 400].float(), atol=3e-2)
+    assert torch.allclose(o.float()[0, 5], vrows[0, 0, 400], atol=3e-2)
 
 
 @pytest.mark.parametrize("epi,flavour,other", [(1, "tanh", "erf"), (2, "erf", "tanh")])

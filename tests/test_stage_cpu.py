@@ -104,29 +104,130 @@ def test_partition_is_a_disjoint_cover():
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
-def test_object_parallel_two_ranks_gloo(tmp_path):
-    names = ["obj__(%d, %d).png" % (i, i) for i in range(5)]
-    cfg, inp, out = make_scene(tmp_path, names)
-    driver = tmp_path / "drv.py"
+def content_factory(config, device):
+    """deterministic CPU stand-in whose mesh is a function of the crop's pixels (a different mesh for every object):
+    a fan of triangles whose vertex coordinates are the crop's first bytes"""
+    import numpy as np
+    from r3g.mesh import Mesh
+
+    class Shape:
+        def __call__(self, image=None, num_inference_steps=None, octree_resolution=None, num_chunks=None,
+                     generator=None, output_type=None):
+            px = np.asarray(image, np.uint8).reshape(-1).astype(np.float32)
+            n = 6 + int(px[0]) % 7
+            v = (px[: 3 * n].reshape(n, 3) / 255.0 + np.arange(n, dtype=np.float32)[:, None] * 0.125).astype(np.float32)
+            f = np.stack([np.zeros(n - 2, np.int64), np.arange(1, n - 1), np.arange(2, n)], 1)
+            return [Mesh(v, f)]
+    return Shape(), (lambda mesh, image=None: mesh), [lambda m: m]
+
+
+def make_distinct_scene(tmp_path, n):
+    cfg, inp, out = make_scene(tmp_path, [])
+    rng = np.random.default_rng(7)
+    names = []
+    for i in range(n):
+        name = "obj__(%d, %d).png" % (i, 3 * i)
+        Image.fromarray(rng.integers(0, 256, (16 + i, 12 + 2 * i, 4), dtype=np.uint8), "RGBA").save(inp / name)
+        names.append(name)
+    return cfg, inp, out, names
+
+
+def _run_ranks(tmp_path, cfg, world, port, factory_name="fake_factory"):
+    driver = tmp_path / ("drv%d.py" % world)
     driver.write_text(textwrap.dedent("""
         import importlib.util, os, sys
         sys.path.insert(0, %r); sys.path.insert(0, %r)
         spec = importlib.util.spec_from_file_location("stage_run", %r)
         stage = importlib.util.module_from_spec(spec); spec.loader.exec_module(stage)
-        from test_stage_cpu import fake_factory
+        import test_stage_cpu as T
         def factory(config, device):
-            s, t, c = fake_factory(config, device)
-            open(os.path.join(%r, "loaded_rank%%s" %% os.environ["RANK"]), "a").write("x")
+            s, t, c = getattr(T, %r)(config, device)
+            open(os.path.join(%r, "loaded_rank%%s" %% os.environ.get("RANK", "0")), "a").write("x")
             return s, t, c
         sys.exit(stage.main(["--config", %r], factory=factory))
-    """ % (os.path.join(ROOT, "3d-re-gen_amd"), os.path.join(ROOT, "tests"), STAGE, str(tmp_path), cfg)))
+    """ % (os.path.join(ROOT, "3d-re-gen_amd"), os.path.join(ROOT, "tests"), STAGE, factory_name, str(tmp_path), cfg)))
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(driver)],
-                       env=env, capture_output=True, text=True, timeout=300)
+    if world == 1:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, str(driver)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(driver)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def test_object_parallel_two_ranks_gloo(tmp_path):
+    names = ["obj__(%d, %d).png" % (i, i) for i in range(5)]
+    cfg, inp, out = make_scene(tmp_path, names)
+    r = _run_ranks(tmp_path, cfg, 2, 29611)
     assert sorted(os.listdir(out)) == sorted(n[:-4] for n in names)       # every object exactly once, stale dir gone
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
-    assert rep["objects"] == 5 and rep["ok"] == 5
+    assert rep["objects"] == 5 and rep["ok"] == 5 and rep["textured"] is True
+    assert sorted(set(rep["rank_of_object"])) <= [0, 1] and len(rep["rank_of_object"]) == 5
     # the model is loaded once per RANK (the reference reloads it per image)
     assert open(tmp_path / "loaded_rank0").read() == "x" and open(tmp_path / "loaded_rank1").read() == "x"
+
+
+def _glbs(out):
+    return {d: (out / d / (d + ".glb")).read_bytes() for d in sorted(os.listdir(out))}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_meshes_are_byte_identical_to_the_one_rank_run(tmp_path, world):
+    """the same inputs at world size 1 and N must give byte-identical GLBs (object-parallel =>
+    exact).  Crops of different sizes and content, scattered by broadcast, claimed dynamically, gathered to rank 0."""
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 7)
+    _run_ranks(tmp_path, cfg, 1, 0, "content_factory")
+    one = _glbs(out)
+    assert sorted(one) == sorted(n[:-4] for n in names)
+    assert len(set(one.values())) == len(names)                  # the stand-in really produces a different mesh per crop
+    r = _run_ranks(tmp_path, cfg, world, 29620 + world, "content_factory")
+    many = _glbs(out)
+    assert many == one
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 7 and rep["ok"] == 7
+
+
+def test_failed_object_does_not_fail_the_distributed_stage(tmp_path):
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 4)
+    r = _run_ranks(tmp_path, cfg, 2, 29631, "flaky_factory")
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 4 and rep["ok"] == 3 and rep["failed"] == [names[2]]
+    assert sorted(os.listdir(out)) == sorted(n[:-4] for i, n in enumerate(names) if i != 2)
+
+
+def flaky_factory(config, device):
+    s, t, c = content_factory(config, device)
+
+    class Flaky:
+        def __call__(self, image=None, **kw):
+            if image.size == (12 + 2 * 2, 16 + 2):        # the third crop of make_distinct_scene
+                raise RuntimeError("synthetic failure")
+            return s(image=image, **kw)
+    return Flaky(), t, c
+
+
+def test_broadcast_crops_and_gather_roundtrip_single_process(tmp_path):
+    """r3g.dist on a world of one (gloo): shapes, dtypes and bytes survive broadcast and gather"""
+    import torch
+    import torch.distributed as dist
+    from r3g import dist as rdist
+    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "rdzv"), rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(0)
+        crops = [rng.integers(0, 256, (5 + i, 9, 4), dtype=np.uint8) for i in range(3)]
+        got = rdist.broadcast_crops(crops)
+        assert [tuple(g.shape) for g in got] == [c.shape for c in crops]
+        assert all(np.array_equal(g.numpy(), c) for g, c in zip(got, crops))
+        q = rdist.WorkQueue(3)
+        assert [q.claim() for _ in range(5)] == [0, 1, 2, None, None]
+        v = np.arange(12, dtype=np.float32).reshape(4, 3)
+        f = np.array([[0, 1, 2], [0, 2, 3]])
+        out = rdist.gather_meshes([(4, torch.from_numpy(v), torch.from_numpy(f)), (1, v[:3], f[:1])])
+        assert sorted(out) == [1, 4] and np.array_equal(out[4][0], v) and out[4][1].dtype == np.int32
+        assert rdist.broadcast_crops([]) == []
+    finally:
+        dist.destroy_process_group()
