@@ -511,11 +511,26 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return r;
 }
 
-constexpr uint32_t P_LIMIT_BF16 = 0x4280u;   // 64.0 as bf16 bits: a larger p triggers the (rare) re-stabilisation
+constexpr float PSUM_LIMIT = 1024.f;   // a block whose 16 p of one lane sum to more (some p > 64) is re-stabilised
 
-template <bool GLDS>
-__global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+// D = A B + C with D in registers DISTINCT from C (hipcc ties vdst to srcC for the builtin and copies the 16 registers
+// of the stabiliser block first: 32 v_mov per key tile).  The s_nop covers a VALU write of an operand just before.
+__device__ __forceinline__ f32x16 mfma_32x32x16_fresh(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    f32x16 d;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// PIPE: software-pipelined body -- the QK^T MFMAs of the NEXT 32-key block are issued ahead of the exponentials of the
+// current one (an in-order wave overlaps its matrix and vector pipes only when the two kinds alternate in program
+// order: ~5 vector instructions fit into the shadow of one 32x32x16 MFMA), two score blocks live, 3-deep K / V^T ring.
+// NW: waves per workgroup (4 or 8), 32 queries each.  All of them share the K / V^T tiles: with 8 waves the stream from
+// L2 into LDS -- measured at ~16 B/clk/CU with three 4-wave workgroups per CU, the most a CU sustains -- is a third.
+// ABL: timing-only ablation mask of the non-pipelined body (1 no exp2, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no LDS-DMA in
+// the loop, 32 no per-tile wait + barrier, 64 no V^T reads, 128 no K reads); results are garbage for ABL != 0.
+template <bool GLDS, bool PIPE, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[(PIPE ? 3 : 2) * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
@@ -525,8 +540,9 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
         const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
-        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + 127) >> 7;
-        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + 127) >> 7 : 0) : ntq0;
+        constexpr int QT = NW * 32;
+        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + QT - 1) / QT;
+        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + QT - 1) / QT : 0) : ntq0;
         const int per_head = p.ragged ? ntq0 + ntq1 : ntq0 * p.B;
         hd = item / per_head;
         int rem = item - hd * per_head;
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
             qt = rem - b * ntq0;
         }
     }
-    const int q = qt * 128 + wid * 32 + ql;
+    const int q = qt * (NW * 32) + wid * 32 + ql;
     const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
@@ -546,9 +562,12 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
     const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
 
     bf16x8 qf[4];
+    {
+        const int qrow = q < p.Lq_pad ? q : p.Lq_pad - 1;   // a 256-query tile may reach past the 128-aligned allocation
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)q * 64 + ks * 16 + hh * 8);
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qrow * 64 + ks * 16 + hh * 8);
+    }
     if (!p.q_prescaled) {   // test entry point with plain Q: fold scale * log2(e) here (a second bf16 rounding)
         const float sc = p.scale * 1.4426950408889634f;
 #pragma unroll
@@ -579,32 +598,197 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
     const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
     const int bias_key = p.ragged ? p.bias_key[b] : -1;
     const float bias_l2 = p.ragged ? p.bias_log2[b] : 0.f;
-    stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, 0, smem, wid, lane, tid);
+    // staging: this lane's two 16-byte chunks of a K tile and of a V^T tile; the per-lane element offsets do not depend on
+    // the tile (wave-uniform tile base + constant lane offset: no vector address arithmetic inside the loop)
+    constexpr int PPW = 8 / NW;   // 1 KiB pieces (8 tile rows) of each of the two tiles per wave
+    int koff[PPW], voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wid * PPW + i) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);
+        koff[i] = row * 64 + kc * 8;
+        voff[i] = row * p.Lk_pad + kc * 8;
+    }
+    auto stage = [&](int t, char* dst) {
+        if constexpr (GLDS) {
+            const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
+            const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (wid * PPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + TILE_B + (wid * PPW + i) * 1024),
+                                                 16, 0, 0);
+            }
+        } else {
+            static_assert(GLDS || NW == 4, "register staging is only built for 4-wave workgroups");
+            stage_kv<false>(Kg, Vtg, p.Lk_pad, t * KV_TILE, dst, wid, lane, tid);
+        }
+    };
+    const bool pad_tail = ntiles * KV_TILE > Lk;
+    if constexpr (PIPE) {
+        // scores of block kb of the tile in LDS slot `buf`; C = the stabiliser block (or zero for the very first block)
+        auto qk = [&](const char* buf, int kb, bool from_zero) {
+            f32x16 sc_;
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(buf + off[kb]);
+            if (from_zero) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                sc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
+            } else {
+                sc_ = mfma_32x32x16_fresh(k0, qf[0], negm);
+            }
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + (off[kb] ^ (ks << 5)));
+                sc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc_, 0, 0, 0);
+            }
+            return sc_;
+        };
+        auto mask_block = [&](f32x16& sc_, int t, int kb) {
+            const int key_base = t * KV_TILE + kb * 32 + 4 * hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key_base + (r & 3) + 8 * (r >> 2);
+                if (key >= Lk) sc_[r] = -INFINITY;
+                else if (key == bias_key) sc_[r] += bias_l2;
+            }
+        };
+        // exponentials, row sum and bf16 packing of one block; `ahead` = the scores already computed (against the same
+        // stabiliser) for the following block, corrected when the stabiliser moves
+        auto softmax_block = [&](f32x16& sc_, f32x16* ahead, uint32_t (&pk)[8]) {
+            float pe[16];
+            float ps0, ps1;
+            auto expsum = [&]() {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(sc_[r]);
+                ps0 = 0.f;
+                ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) { ps0 += pe[r]; ps1 += pe[r + 1]; }
+                ps0 += ps1;
+            };
+            expsum();
+            if (__any(!(ps0 <= PSUM_LIMIT))) {   // rare: re-stabilise before anything of this block is used
+                float mx = sc_[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc_[r]);
+                const float grow = fmaxf(half_max(mx), 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-grow);
+                m_run += grow;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] = -m_run; sc_[r] -= grow; }
+                if (ahead) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) (*ahead)[r] -= grow;
+                }
+                expsum();
+            }
+            l_run += ps0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
+        };
+        auto pv = [&](const char* buf, int kb, const uint32_t (&pk)[8]) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pk[4 * ks2 + e];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(buf + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
+                }
+            }
+        };
+        stage(0, smem);
+        if (ntiles > 1) stage(1, smem + STAGE_B);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // very first block: scores from zero, exact maximum as the initial stabiliser
+        f32x16 sA = qk(smem, 0, true), sB;
+        if (ntiles == 1 && pad_tail) mask_block(sA, 0, 0);
+        {
+            float mx = sA[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sA[r]);
+            m_run = half_max(mx);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sA[r] -= m_run; }
+        }
+        auto tile = [&](auto masked, auto has_next, const int t, const int slot) {
+            const char* cur = smem + slot * STAGE_B;
+            const char* nxt = smem + (slot == 2 ? 0 : slot + 1) * STAGE_B;
+            if (t + 2 < ntiles) stage(t + 2, smem + (slot == 0 ? 2 : slot - 1) * STAGE_B);
+            uint32_t pk[8];
+            // block 0 of this tile (scores sA, computed one step ago); block 1's scores are issued first
+            sB = qk(cur, 1, false);
+            if constexpr (decltype(masked)::value) {
+                if (t > 0) mask_block(sA, t, 0);     // (the single-tile case masked its first block in the prologue)
+                mask_block(sB, t, 1);
+            }
+            softmax_block(sA, &sB, pk);
+            pv(cur, 0, pk);
+            // block 1 (scores sB); the first block of the next tile is issued first
+            if constexpr (decltype(has_next)::value) {
+                sA = qk(nxt, 0, false);
+                softmax_block(sB, &sA, pk);
+            } else {
+                softmax_block(sB, nullptr, pk);
+            }
+            pv(cur, 1, pk);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        int slot = 0;
+        for (int t = 0; t < ntiles - 1; ++t) {
+            tile(std::false_type{}, std::true_type{}, t, slot);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1, slot);
+        else tile(std::false_type{}, std::false_type{}, ntiles - 1, slot);
+    } else {
+    stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     auto tile = [&](auto masked, auto first, const int t) {
         const char* cur = smem + (t & 1) * STAGE_B;
-        if (t + 1 < ntiles) stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, (t + 1) * KV_TILE, smem + ((t + 1) & 1) * STAGE_B, wid, lane, tid);
+        if (!(ABL & 16) && t + 1 < ntiles) stage(t + 1, smem + ((t + 1) & 1) * STAGE_B);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             constexpr bool kFirst = decltype(first)::value;
             const bool first_block = kFirst && kb == 0;
             // ---- scores of 32 keys (log2 units, already minus the stabiliser unless this is the very first block)
             f32x16 s;
-            {
-                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cur + off[kb]);
+            if constexpr ((ABL & 8) != 0) {
+                const float tv = __int_as_float(0x3f800000 + (t << 8));   // varies with the tile: not loop invariant
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = negm[r] + tv * (float)(r + 1) * 1e-3f;
+                if (!(ABL & 128)) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + (off[kb] ^ (ks << 5)));
+                        asm volatile("" ::"v"(kf));
+                    }
+                }
+            } else {
+                const bf16x8 k0 = (ABL & 128) ? qf[1] : *reinterpret_cast<const bf16x8*>(cur + off[kb]);
                 if (first_block) {
                     f32x16 z;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
                 } else {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], negm, 0, 0, 0);
+                    s = mfma_32x32x16_fresh(k0, qf[0], negm);
                 }
 #pragma unroll
                 for (int ks = 1; ks < 4; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + (off[kb] ^ (ks << 5)));
+                    const bf16x8 kf = (ABL & 128) ? qf[(ks + 1) & 3]
+                                                  : *reinterpret_cast<const bf16x8*>(cur + (off[kb] ^ (ks << 5)));
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
                 }
             }
@@ -629,16 +813,23 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
             uint32_t pk[8];
             auto exponentiate = [&]() {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(s[r]);
+                for (int r = 0; r < 16; ++r) pe[r] = (ABL & 1) ? s[r] * 0.001f : __builtin_amdgcn_exp2f(s[r]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
             };
+            float ps0, ps1;
+            auto row_sum = [&]() {
+                ps0 = 0.f;
+                ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) { ps0 += pe[r]; ps1 += pe[r + 1]; }
+                ps0 += ps1;
+            };
             exponentiate();
+            row_sum();
             if (!first_block) {
-                uint32_t pm = pk_max_u16(pk_max_u16(pk_max_u16(pk[0], pk[1]), pk_max_u16(pk[2], pk[3])),
-                                         pk_max_u16(pk_max_u16(pk[4], pk[5]), pk_max_u16(pk[6], pk[7])));
-                pm = (pm >> 16) > (pm & 0xFFFFu) ? (pm >> 16) : (pm & 0xFFFFu);
-                if (__any(pm > P_LIMIT_BF16)) {
+                // sum >= max: a small sum proves that no p is large (and inf / NaN fail the comparison)
+                if (__any(!(ps0 <= PSUM_LIMIT))) {
                     // rare: some query's scores outgrew its stabiliser.  s is relative to the old one: the growth is the
                     // block maximum itself.  Nothing of this block has entered O or l yet.
                     float mx = s[0];
@@ -651,12 +842,10 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] = -m_run; s[r] -= grow; }
                     exponentiate();
+                    row_sum();
                 }
             }
-            float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) { ps0 += pe[r]; ps1 += pe[r + 1]; }
-            l_run += ps0 + ps1;
+            l_run += ps0;
             // ---- O^T += V^T P^T for these 32 keys: the lane's 8 keys of each 16-key group are one 16-byte chunk of V^T
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -665,15 +854,18 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
                 for (int e = 0; e < 4; ++e) pf.u[e] = pk[4 * ks2 + e];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
+                    const bf16x8 vf = (ABL & 64) ? qf[(ks2 + db) & 3]
+                                                 : *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
+                    if (ABL & 4) asm volatile("" ::"v"(vf), "v"(pf.v));
+                    else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(ABL & 32)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
-    const bool pad_tail = ntiles * KV_TILE > Lk;
     if (ntiles == 1) {
         if (pad_tail) tile(std::true_type{}, std::true_type{}, 0);
         else tile(std::false_type{}, std::true_type{}, 0);
@@ -683,6 +875,7 @@ __global__ __launch_bounds__(256, 3) void attn2_kernel(AttnArgs p) {
         if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1);
         else tile(std::false_type{}, std::false_type{}, ntiles - 1);
     }
+    }   // !PIPE
 
     const float inv = 1.0f / half_sum(l_run);
     {
@@ -722,8 +915,8 @@ void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 
 static int g_attn_gen = 2;
-void attn_set_generation(int gen) { if (gen == 1 || gen == 2) g_attn_gen = gen; }
-float attn_q_scale(float scale) { return g_attn_gen == 2 ? scale * 1.4426950408889634f : 1.0f; }
+void attn_set_generation(int gen) { if (gen >= 1 && gen <= 5) g_attn_gen = gen; }
+float attn_q_scale(float scale) { return g_attn_gen >= 2 ? scale * 1.4426950408889634f : 1.0f; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.ragged) {
@@ -743,13 +936,28 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         for (int b = 0; b < p.B; ++b) pairs += (double)p.lq_b[b] * p.lk_b[b];
     }
     ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
-    if (g_attn_gen == 2 && !g_attn_ablate && !g_attn_pipelined) {
+    if (g_attn_gen >= 2 && !g_attn_pipelined) {
+        // generation: 2 = 4 waves, 3 = 4 waves software-pipelined, 4 = 8 waves software-pipelined, 5 = 8 waves
+        const int nw = (g_attn_glds && g_attn_gen >= 4) ? 8 : 4, qtile = nw * 32;
         int items = 0;
-        if (p.ragged) for (int b = 0; b < p.B; ++b) items += (p.lq_b[b] + 127) / 128;
-        else items = ((p.Lq + 127) / 128) * p.B;
+        if (p.ragged) for (int b = 0; b < p.B; ++b) items += (p.lq_b[b] + qtile - 1) / qtile;
+        else items = ((p.Lq + qtile - 1) / qtile) * p.B;
         items *= p.H;
-        if (g_attn_glds) hipLaunchKernelGGL(attn2_kernel<true>, dim3(items), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(attn2_kernel<false>, dim3(items), dim3(256), 0, s, p);
+        if (g_attn_ablate && g_attn_gen == 2) {
+            switch (g_attn_ablate) {
+#define R3G_ABL2(m) case m: hipLaunchKernelGGL((attn2_kernel<true, false, 4, m>), dim3(items), dim3(256), 0, s, p); break;
+                R3G_ABL2(1) R3G_ABL2(4) R3G_ABL2(8) R3G_ABL2(12) R3G_ABL2(16) R3G_ABL2(48) R3G_ABL2(64) R3G_ABL2(128)
+                R3G_ABL2(192) R3G_ABL2(240) R3G_ABL2(241) R3G_ABL2(245) R3G_ABL2(253)
+#undef R3G_ABL2
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+        if (!g_attn_glds) hipLaunchKernelGGL((attn2_kernel<false, false, 4>), dim3(items), dim3(256), 0, s, p);
+        else if (g_attn_gen == 3) hipLaunchKernelGGL((attn2_kernel<true, true, 4>), dim3(items), dim3(256), 0, s, p);
+        else if (g_attn_gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
+        else if (g_attn_gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
         return hipGetLastError();
     }
     if (p.q_prescaled) return hipErrorInvalidValue;   // the first-generation kernels scale the scores themselves

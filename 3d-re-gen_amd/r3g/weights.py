@@ -113,20 +113,32 @@ def _is_scale(name):
                 "norm1.", "norm2.", "q_norm.", "k_norm.", "ln_1.", "ln_2.", "ln_3.", "ln_post.", "layernorm."))))
 
 
-def synthetic_state_dict(cfg, seed=0, device="cuda", std=0.02):
-    """Seeded synthetic checkpoint generated on `device` (timing / plumbing): Linear ~ N(0, std^2),
-    norm scales 1 +- 5 %, small biases, non-zero modulation / gate layers, output_proj std 0.2."""
+def synthetic_state_dict(cfg, seed=0, device="cuda", std=None):
+    """Seeded synthetic checkpoint generated on `device` (timing / plumbing).  Default: every layer at
+    unit scale -- Linear ~ N(0, 1/fan_in), adaLN modulation layers ~ N(0, 9/fan_in) with bias N(0, 0.3^2), norm scales
+    1 +- 10 %, biases N(0, 0.1^2), Dinov2 cls / position embeddings N(0, 0.5^2) -- so that every branch contributes O(1)
+    to its residual stream and the occupancy field changes sign (a surface exists at every model size).
+    std = 0.02 (a float) reproduces the first-round checkpoint: Linear ~ N(0, std^2), near-identity blocks."""
     g = torch.Generator(device=device).manual_seed(seed)
     sd = {}
     for name, shape in param_shapes(cfg).items():
+        is_mod = ".lin." in name or "adaLN" in name
+        emb = name.endswith(("cls_token", "mask_token", "position_embeddings"))
         if _is_scale(name):
-            t = 1.0 + 0.05 * torch.randn(shape, generator=g, device=device)
-        elif len(shape) >= 2 and not name.endswith(("cls_token", "mask_token", "position_embeddings")):
-            t = (0.2 if "output_proj" in name else std) * torch.randn(shape, generator=g, device=device)
-        elif name.endswith(("cls_token", "position_embeddings")):
-            t = std * torch.randn(shape, generator=g, device=device)
+            t = 1.0 + (0.1 if std is None else 0.05) * torch.randn(shape, generator=g, device=device)
+        elif emb:
+            t = (0.5 if std is None else std) * torch.randn(shape, generator=g, device=device)
+        elif len(shape) >= 2:
+            if std is None:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                scale = (3.0 if is_mod else 1.0) / fan_in ** 0.5
+            else:
+                scale = 0.2 if "output_proj" in name else std
+            t = scale * torch.randn(shape, generator=g, device=device)
         else:
-            t = 0.01 * torch.randn(shape, generator=g, device=device)
+            t = ((0.3 if is_mod else 0.1) if std is None else 0.01) * torch.randn(shape, generator=g, device=device)
         sd[name] = t
     return sd
 

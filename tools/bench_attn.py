@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--shapes", default="0,1")
     ap.add_argument("--gens", default="", help="comma list of attn_generation values to time instead of ablation masks")
+    ap.add_argument("--gen", type=int, default=2, help="kernel generation the ablation masks apply to")
+    ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power sensitivity)")
     a = ap.parse_args()
     masks = [int(m) for m in (a.gens or a.ablate).split(",")]
     ffi.context(0)
@@ -41,6 +43,10 @@ def main():
         K = torch.randn(1 if shared else B, H, lkp, 64, device="cuda", generator=g).to(torch.bfloat16)
         Vt = torch.randn(1 if shared else B, H, 64, lkp, device="cuda", generator=g).to(torch.bfloat16)
         o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
+        if a.zero:
+            Q.zero_(); K.zero_(); Vt.zero_()
+        if not a.gens:
+            ffi.check(L.r3g_set_option(b"attn_generation", a.gen))
 
         def run(mask):
             if a.gens:
@@ -64,7 +70,7 @@ def main():
         fl = 4.0 * B * H * Lq * Lk * 64
         for m, ts in times.items():
             med = statistics.median(ts)
-            print(json.dumps(dict(op="attn", B=B, H=H, Lq=Lq, Lk=Lk, ablate=m, us_med=1e3 * med, us_min=1e3 * min(ts),
+            print(json.dumps(dict(op="attn", B=B, H=H, Lq=Lq, Lk=Lk, zero=a.zero, **({"gen": m} if a.gens else {"gen": a.gen, "ablate": m}), us_med=1e3 * med, us_min=1e3 * min(ts),
                                   tflops_med=fl / med / 1e9)), flush=True)
     ffi.check(L.r3g_set_option(b"attn_ablate", 0))
     ffi.check(L.r3g_set_option(b"attn_generation", 2))

@@ -21,6 +21,15 @@ if which == "gemm":
     c = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, None, c.data_ptr(), N, None, M, N, K, 0, 1, s))
+elif which == "gemm8":   # the phased 256x256 kernel on one shape: gemm8 M N K epilogue
+    M, N, K, epi = (int(x) for x in sys.argv[2:6])
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda")
+    c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi >= 3 else torch.bfloat16)
+    ffi.check(L.r3g_set_option(b"gemm_waves", 11))
+    for _ in range(3):
+        ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N, None, M, N, K, epi, 1, s))
 else:
     B, H, Lq, Lk = 2, 16, 4442, 4442
     lqp, lkp = 4480, 4480
