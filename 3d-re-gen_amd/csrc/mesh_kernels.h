@@ -17,8 +17,12 @@ hipError_t mesh_remove_floaters(char* ws, size_t ws_bytes, unsigned* h_small, fl
                                 int32_t* faces, int64_t* nf_io, double min_ratio, hipStream_t s);
 hipError_t mesh_remove_degenerate(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
                                   int32_t* faces, int64_t* nf_io, hipStream_t s);
+// quadric-error-metric edge collapse (the algorithm class upstream's FaceReducer uses); *rounds_out (optional) = rounds
 hipError_t mesh_reduce_faces(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
-                             int32_t* faces, int64_t* nf_io, int64_t max_faces, hipStream_t s);
+                             int32_t* faces, int64_t* nf_io, int64_t max_faces, int* rounds_out, hipStream_t s);
+// uniform-grid vertex clustering (round 1's reducer; kept as the bit-exactly restated alternative)
+hipError_t mesh_cluster_faces(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
+                              int32_t* faces, int64_t* nf_io, int64_t max_faces, hipStream_t s);
 
 }  // namespace r3g
 #endif

@@ -25,6 +25,10 @@
 
 #pragma clang fp contract(off)
 
+#define R3G_QEM_HD static __host__ __device__ __forceinline__
+#define R3G_QEM_LAMBDA __device__
+#include "qem_driver.h"
+
 namespace r3g {
 namespace {
 
@@ -466,7 +470,15 @@ size_t mesh_workspace_bytes(int64_t nv, int64_t nf, int64_t max_cells) {
     add(24 * (size_t)nv);          // cluster sums
     add(4 * (size_t)nv);           // cluster counts
     add(256);                      // small results
-    return b + 4096;
+    // the edge-collapse decimator (qem_driver.h Buffers)
+    size_t q = 0;
+    auto addq = [&](size_t bytes) { q += (bytes + 255) & ~(size_t)255; };
+    addq(256);
+    addq(4 * (size_t)nv); addq(4 * (size_t)(nv + 1)); addq(12 * (size_t)nf); addq(80 * (size_t)nv); addq((size_t)nv);
+    addq(4 * (size_t)nv); addq(8 * (size_t)nv); addq(4 * (size_t)nv); addq(8 * (size_t)nv); addq(4 * (size_t)nv);
+    addq(4 * (size_t)nv); addq(4 * (size_t)m); addq(4 * (size_t)m); addq(12 * (size_t)nf); addq(12 * (size_t)nv);
+    addq(4 * (size_t)nv); addq(4 * scan_scratch_elems(3 * nf > m ? 3 * nf : m));
+    return (b > q ? b : q) + 4096;
 }
 
 // Shared tail: drop the faces with keep == 0 and the vertices no kept face references (order preserved).
@@ -542,8 +554,8 @@ int mesh_reduce_initial_res(int64_t max_faces) {
     return r < 4 ? 4 : r;
 }
 
-hipError_t mesh_reduce_faces(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
-                             int32_t* faces, int64_t* nf_io, int64_t max_faces, hipStream_t s) {
+hipError_t mesh_cluster_faces(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
+                              int32_t* faces, int64_t* nf_io, int64_t max_faces, hipStream_t s) {
     const int64_t nv = *nv_io, nf = *nf_io;
     if (nv == 0 || nf == 0 || nf <= max_faces) return hipSuccess;
     ProfScope ps(PC_MESH, 12.0 * (double)(nv + nf), s);
@@ -627,6 +639,93 @@ hipError_t mesh_reduce_faces(char* ws, size_t ws_bytes, unsigned* h_small, float
     *nv_io = h_small[0];
     R3G_HIP(hipMemcpyAsync(faces, fout, 12 * (size_t)*nf_io, hipMemcpyDeviceToDevice, s));
     R3G_HIP(hipMemcpyAsync(verts, vout, 12 * (size_t)*nv_io, hipMemcpyDeviceToDevice, s));
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ quadric edge collapse (qem_core.h / qem_driver.h)
+namespace {
+
+template <class F>
+__global__ __launch_bounds__(kT) void parfor_kernel(F f, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i < n) f(i);
+}
+
+__global__ __launch_bounds__(kT) void sum_if_kernel(const uint32_t* __restrict__ w, const uint64_t* __restrict__ key,
+                                                     int64_t n, uint64_t thr, unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < n && w[i] && key[i] <= thr) v = w[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+struct HipBackend {
+    hipStream_t s;
+    unsigned* bsum;
+    unsigned* d_small;     // >= 16 bytes
+    unsigned* h_small;     // pinned
+    hipError_t err = hipSuccess;
+    struct Atomics {
+        __device__ static uint32_t inc(uint32_t* p) { return atomicAdd(p, 1u); }
+    };
+    void note(hipError_t e) { if (err == hipSuccess && e != hipSuccess) err = e; }
+    template <class F>
+    void parfor(int64_t n, F f) {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(parfor_kernel<F>, dim3(nblocks(n, kT)), dim3(kT), 0, s, f, n);
+    }
+    uint32_t scan(const uint32_t* in, int64_t n, uint32_t* out) {
+        if (n <= 0) return 0;
+        note(exclusive_scan(in, n, out, bsum, d_small, s));
+        note(hipMemcpyAsync(h_small, d_small, 4, hipMemcpyDeviceToHost, s));
+        note(hipStreamSynchronize(s));
+        return h_small[0];
+    }
+    uint64_t sum_if(const uint32_t* w, const uint64_t* key, int64_t n, uint64_t thr) {
+        note(hipMemsetAsync(d_small + 2, 0, 8, s));
+        hipLaunchKernelGGL(sum_if_kernel, dim3(nblocks(n, kT)), dim3(kT), 0, s, w, key, n, thr,
+                           (unsigned long long*)(d_small + 2));
+        note(hipMemcpyAsync(h_small + 2, d_small + 2, 8, hipMemcpyDeviceToHost, s));
+        note(hipStreamSynchronize(s));
+        return *(const unsigned long long*)(h_small + 2);
+    }
+    void zero(void* p, size_t bytes) { if (bytes) note(hipMemsetAsync(p, 0, bytes, s)); }
+    void copy(void* dst, const void* src, size_t bytes) {
+        if (bytes) note(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    }
+};
+
+}  // namespace
+
+// FaceReducer: quadric-error-metric edge collapse down to <= max_faces faces (see qem_core.h)
+hipError_t mesh_reduce_faces(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
+                             int32_t* faces, int64_t* nf_io, int64_t max_faces, int* rounds_out, hipStream_t s) {
+    const int64_t nv = *nv_io, nf = *nf_io;
+    if (rounds_out) *rounds_out = 0;
+    if (nv == 0 || nf == 0 || nf <= max_faces) return hipSuccess;
+    ProfScope ps(PC_MESH, 12.0 * (double)(nv + nf), s);
+    Arena ar = {ws, 0, ws_bytes};
+    const int64_t m = nv > nf ? nv : nf;
+    HipBackend be{s, nullptr, ar.take<unsigned>(16), h_small};
+    r3g_qem::Buffers b;
+    b.verts = verts; b.faces = faces;
+    b.deg = ar.take<uint32_t>(nv); b.off = ar.take<uint32_t>(nv + 1); b.adj = ar.take<int32_t>(3 * nf);
+    b.quad = ar.take<double>(10 * nv); b.bnd = ar.take<uint8_t>(nv); b.partner = ar.take<int32_t>(nv);
+    b.key = ar.take<uint64_t>(nv); b.mark_lo = ar.take<int32_t>(nv); b.mark_key = ar.take<uint64_t>(nv);
+    b.sel = ar.take<uint32_t>(nv); b.remap = ar.take<int32_t>(nv); b.keep = ar.take<uint32_t>(m);
+    b.pos = ar.take<uint32_t>(m); b.faces_tmp = ar.take<int32_t>(3 * nf); b.verts_tmp = ar.take<float>(3 * nv);
+    b.used = ar.take<uint32_t>(nv);
+    be.bsum = ar.take<unsigned>((int64_t)scan_scratch_elems(3 * nf > m ? 3 * nf : m));
+    if (ar.off > ws_bytes) return hipErrorOutOfMemory;
+    const r3g_qem::Result r = r3g_qem::decimate(be, b, nv, nf, max_faces);
+    R3G_HIP(be.err);
+    R3G_HIP(hipGetLastError());
+    R3G_HIP(hipStreamSynchronize(s));
+    *nv_io = r.nv;
+    *nf_io = r.nf;
+    if (rounds_out) *rounds_out = r.rounds;
     return hipSuccess;
 }
 

@@ -177,13 +177,26 @@ int r3g_mesh_reduce_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_
     if (rc) return rc;
     if (max_faces < 1 || max_faces > 200000000) return fail(R3G_ERR_INVALID, "r3g_mesh_reduce_faces: max_faces out of range");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    rc = c->reserve(&c->mesh_ws, &c->mesh_ws_bytes, mesh_workspace_bytes(*n_verts, *n_faces, 0), "hipMalloc(mesh workspace)");
+    if (rc) return rc;
+    hipError_t e = mesh_reduce_faces(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
+                                     n_faces, max_faces, nullptr, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_reduce_faces");
+}
+
+int r3g_mesh_cluster_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                           int64_t max_faces, void* stream) {
+    int rc = mesh_args("r3g_mesh_cluster_faces", ctx, d_verts, n_verts, d_faces, n_faces);
+    if (rc) return rc;
+    if (max_faces < 1 || max_faces > 200000000) return fail(R3G_ERR_INVALID, "r3g_mesh_cluster_faces: max_faces out of range");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
     const int64_t r = mesh_reduce_initial_res(max_faces);
     rc = c->reserve(&c->mesh_ws, &c->mesh_ws_bytes, mesh_workspace_bytes(*n_verts, *n_faces, r * r * r),
                     "hipMalloc(mesh workspace)");
     if (rc) return rc;
-    hipError_t e = mesh_reduce_faces(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
-                                     n_faces, max_faces, (hipStream_t)stream);
-    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_reduce_faces");
+    hipError_t e = mesh_cluster_faces(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
+                                      n_faces, max_faces, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_cluster_faces");
 }
 
 }  // extern "C"

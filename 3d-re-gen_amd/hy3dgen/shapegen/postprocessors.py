@@ -4,8 +4,9 @@ here the mesh stays in HBM where marching cubes left it and the cleaners are HIP
 cleaners", csrc/mesh_kernels.hip):
   FloaterRemover        : drop connected components smaller than 0.5 % of the largest (by face count)
   DegenerateFaceRemover : drop faces with repeated vertices and unreferenced vertices
-  FaceReducer           : reduce to <= max_facenum faces (vertex clustering on a uniform grid; upstream
-                          uses quadric edge collapse -- geometric, not bit-wise, equivalence)
+  FaceReducer           : reduce to <= max_facenum faces by quadric-error-metric edge collapse (upstream: MeshLab
+                          meshing_decimation_quadric_edge_collapse with boundary / normal / topology preservation);
+                          equivalence with MeshLab's sequential queue is geometric, not index-wise
 There is no CPU path: a mesh that only has host arrays is uploaded first, and without a GPU the call raises.
 Per-vertex colours are not carried through (marching-cubes meshes have none).
 """

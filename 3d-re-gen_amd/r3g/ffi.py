@@ -39,6 +39,7 @@ SYMBOLS = {
     "r3g_mesh_remove_floaters": (_I, [_P, _P, _I64P, _P, _I64P, _D, _P]),
     "r3g_mesh_remove_degenerate": (_I, [_P, _P, _I64P, _P, _I64P, _P]),
     "r3g_mesh_reduce_faces": (_I, [_P, _P, _I64P, _P, _I64P, ctypes.c_int64, _P]),
+    "r3g_mesh_cluster_faces": (_I, [_P, _P, _I64P, _P, _I64P, ctypes.c_int64, _P]),
     "r3g_model_create": (_I, [_P, _P]),
     "r3g_model_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
     "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),

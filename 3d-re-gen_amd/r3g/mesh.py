@@ -117,6 +117,19 @@ class Mesh:
         used[self.faces.reshape(-1)] = True
         self.update_vertices(used)
 
+    def simplify_quadric_decimation(self, face_count=None, percent=None, **kwargs):
+        """trimesh.Trimesh.simplify_quadric_decimation as the reference's remesh step calls it (run.py:47-49): a new mesh
+        with <= face_count faces by quadric edge collapse -- the GPU decimator of r3g.meshops (there is no CPU path)"""
+        from . import meshops
+        if face_count is None:
+            if percent is None:
+                raise ValueError("face_count or percent is required")
+            face_count = int(self.n_faces * (1.0 - float(percent)))
+        if self.is_empty or self.n_faces <= face_count:
+            return self.copy()
+        v, f = meshops.reduce_faces(*self.device_buffers(), int(face_count))
+        return Mesh.from_device(v, f, self.metadata)
+
     def process(self, validate=False):
         """merge bit-identical vertices (trimesh.Trimesh.process default), drop degenerate faces if validate"""
         if len(self.vertices):

@@ -41,4 +41,17 @@ def remove_degenerate(verts, faces):
 
 
 def reduce_faces(verts, faces, max_faces=40000):
-    return _run(ffi.lib().r3g_mesh_reduce_faces, verts, faces, ctypes.c_int64(int(max_faces)))
+    """FaceReducer: quadric-error-metric edge collapse down to <= max_faces faces; closed surfaces stay closed manifolds
+    of the same genus, boundaries stay boundaries (csrc/qem_core.h).  A budget the topology cannot reach (fewer faces
+    than the components need) is reported with a warning, never silently."""
+    v, f = _run(ffi.lib().r3g_mesh_reduce_faces, verts, faces, ctypes.c_int64(int(max_faces)))
+    if f.shape[0] > max_faces:
+        import warnings
+        warnings.warn("r3g.meshops.reduce_faces: stopped at %d faces, above the budget of %d: no further collapse keeps "
+                      "the mesh a manifold" % (f.shape[0], max_faces), RuntimeWarning)
+    return v, f
+
+
+def cluster_faces(verts, faces, max_faces=40000):
+    """vertex clustering on a uniform grid (round 1's reducer: robust on triangle soups, does not preserve topology)"""
+    return _run(ffi.lib().r3g_mesh_cluster_faces, verts, faces, ctypes.c_int64(int(max_faces)))

@@ -102,7 +102,6 @@ def default_factory(config, device):
 def clean_and_validate_mesh(mesh, min_faces=10, target_face_count=None):
     """reference clean_and_validate_trimesh :24-64 on the Trimesh-like r3g.mesh.Mesh"""
     import numpy as np
-    from hy3dgen.shapegen import FaceReducer
     if mesh is None or mesh.is_empty:
         raise ValueError("Input is not a valid or is an empty trimesh object.")
     ok = np.all(np.isfinite(mesh.vertices), axis=1)
@@ -110,7 +109,9 @@ def clean_and_validate_mesh(mesh, min_faces=10, target_face_count=None):
         print("[WARN] Found %d invalid (NaN/Inf) vertices. Cleaning..." % int((~ok).sum()))
         mesh.update_vertices(ok)
     if target_face_count is not None and len(mesh.faces) > target_face_count:
-        mesh = FaceReducer()(mesh, max_facenum=target_face_count)
+        print("Simplifying mesh from %d to %d faces..." % (len(mesh.faces), target_face_count))
+        mesh = mesh.simplify_quadric_decimation(face_count=target_face_count)
+        print("Simplified mesh has %d faces." % len(mesh.faces))
     if mesh.is_empty or len(mesh.faces) < min_faces:
         raise ValueError("Mesh is empty or has fewer than %d faces after cleaning/simplification." % min_faces)
     mesh.process(validate=True)

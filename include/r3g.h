@@ -81,18 +81,27 @@ int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xf
  *   remove_floaters  : drops every connected component (vertices joined by a face) with fewer faces than
  *                      max(1, ceil(min_ratio * faces of the largest component)), then unreferenced vertices.
  *   remove_degenerate: drops faces with a repeated vertex index, then unreferenced vertices.
- *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise vertex clustering on a uniform grid over the
- *                      bounding box (first resolution floor(sqrt(max_faces / 2.2)), shrunk by 0.9 until the face
- *                      budget holds, at most 24 times): a cluster's vertex is the mean of its members, faces
- *                      that collapse or repeat an earlier face's vertex set are dropped.  (Upstream uses quadric
- *                      edge collapse: equivalence with it is geometric, not index-wise.)
- * The results are pure functions of the input: oracle/mesh_clean.py reproduces them bit for bit. */
+ *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise quadric-error-metric edge collapse (the algorithm
+ *                      class of upstream's MeshLab filter) in rounds of independent collapses: every vertex picks its
+ *                      cheapest valid edge (optimal placement; link condition, no face turning by more than ~78
+ *                      degrees, no slivers, boundary vertices stay on the boundary), mutually chosen edges whose
+ *                      neighbourhoods do not overlap collapse simultaneously, the last round is cut at the key that
+ *                      meets the budget (result within 1 % below max_faces).  Closed surfaces stay closed manifolds
+ *                      of the same genus.  Equivalence with MeshLab is geometric, not index-wise.
+ *   cluster_faces    : vertex clustering on a uniform grid over the bounding box (first resolution
+ *                      floor(sqrt(max_faces / 2.2)), shrunk by 0.9 until the face budget holds, at most 24 times): a
+ *                      cluster's vertex is the mean of its members, faces that collapse or repeat an earlier face's
+ *                      vertex set are dropped.  Robust on triangle soups; does not preserve topology.
+ * The results are pure functions of the input: oracle/mesh_clean.py reproduces floaters / degenerate / cluster bit for
+ * bit, tests/emu/qem_emu.cpp (the same per-element code in host loops) the edge collapse. */
 int r3g_mesh_remove_floaters(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
                              double min_ratio, void* stream);
 int r3g_mesh_remove_degenerate(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
                                void* stream);
 int r3g_mesh_reduce_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
                           int64_t max_faces, void* stream);
+int r3g_mesh_cluster_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
+                           int64_t max_faces, void* stream);
 
 /* ---- shape model (DiT + ShapeVAE + DINOv2 conditioner) -----------------------------------------
  * Replaces the modules `Hunyuan3DDiTFlowMatchingPipeline.from_pretrained` instantiates from the

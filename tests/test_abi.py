@@ -87,3 +87,14 @@ def test_binding_matches_the_prototypes():
             assert res is None, name
         else:
             assert res is ctypes.c_int, name
+
+
+def test_library_was_built_from_these_sources():
+    """libr3g.so travels to the GPU box prebuilt (it is git-ignored but part of the snapshot): the digest stamped beside it
+    by 3d-re-gen_amd/build.py must equal the digest of the sources, headers and flags in this tree"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("r3g_build", os.path.join(ROOT, "3d-re-gen_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.built_digest() is not None, "libr3g.digest missing: run python 3d-re-gen_amd/build.py"
+    assert b.built_digest() == b.source_digest(), "libr3g.so is stale: rebuild with python 3d-re-gen_amd/build.py"

@@ -65,19 +65,19 @@ def test_soup(nv, nf, seed):
     hv, hf = v.cpu().numpy(), f.cpu().numpy()
     _same(meshops.remove_degenerate(v, f), mesh_clean.remove_degenerate(hv, hf))
     _same(meshops.remove_floaters(v, f, 0.3), mesh_clean.remove_floaters(hv, hf, 0.3))
-    _same(meshops.reduce_faces(v, f, max(1, nf // 10)), mesh_clean.reduce_faces(hv, hf, max(1, nf // 10)))
+    _same(meshops.cluster_faces(v, f, max(1, nf // 10)), mesh_clean.reduce_faces(hv, hf, max(1, nf // 10)))
 
 
 @pytest.mark.parametrize("n,budget", [(65, 3000), (129, 40000), (129, 500)])
-def test_reduce_on_mc_mesh(n, budget):
+def test_cluster_on_mc_mesh(n, budget):
     from oracle import mesh_clean
     from r3g import meshops
     v, f = _mc_mesh(n, 3, floaters=0)
     want = mesh_clean.reduce_faces(v.cpu().numpy(), f.cpu().numpy(), budget)
-    got = meshops.reduce_faces(v, f, budget)
+    got = meshops.cluster_faces(v, f, budget)
     assert 0 < len(want[1]) <= budget
     _same(got, want)
-    again = meshops.reduce_faces(*got, budget)            # already within budget: untouched
+    again = meshops.cluster_faces(*got, budget)           # already within budget: untouched
     _same(again, want)
 
 
@@ -94,6 +94,7 @@ def test_inputs_untouched_and_empty():
 
 
 def test_postprocessor_classes_keep_the_mesh_on_the_gpu():
+    import emu_qem
     from hy3dgen.shapegen import DegenerateFaceRemover, FaceReducer, FloaterRemover
     from oracle import mesh_clean
     from r3g.mesh import Mesh
@@ -104,11 +105,11 @@ def test_postprocessor_classes_keep_the_mesh_on_the_gpu():
     assert m._v is None and m.n_faces <= 40000            # nothing was downloaded on the way
     w = mesh_clean.remove_floaters(v.cpu().numpy(), f.cpu().numpy())
     w = mesh_clean.remove_degenerate(*w)
-    w = mesh_clean.reduce_faces(*w, 40000)
+    w = emu_qem.reduce_faces(*w, 40000)                   # FaceReducer = quadric edge collapse (tests/emu/qem_emu.cpp)
     assert np.array_equal(m.faces, w[1]) and np.array_equal(m.vertices.astype(np.float32), w[0])
     host = Mesh(v.cpu().numpy(), f.cpu().numpy())         # host-born mesh: uploaded, same answer
     h = FaceReducer()(host, max_facenum=2000)
-    w2 = mesh_clean.reduce_faces(v.cpu().numpy(), f.cpu().numpy(), 2000)
+    w2 = emu_qem.reduce_faces(v.cpu().numpy(), f.cpu().numpy(), 2000)
     assert np.array_equal(h.faces, w2[1])
     data = h.export(file_type="glb")
     assert data[:4] == b"glTF"
@@ -143,7 +144,8 @@ def test_full_size_properties():
     rv, rf = meshops.reduce_faces(fv, ff, 40000)
     assert rf.shape[0] <= 40000
     lo_b, hi_b = fv.min(0).values, fv.max(0).values
-    assert (rv >= lo_b - 1e-6).all() and (rv <= hi_b + 1e-6).all()      # cluster means stay inside the bounding box
+    ext = (hi_b - lo_b).max()
+    assert (rv >= lo_b - 0.01 * ext).all() and (rv <= hi_b + 0.01 * ext).all()   # optimal placements stay at the surface
 
 
 def test_results_do_not_depend_on_scheduling():
@@ -155,8 +157,8 @@ def test_results_do_not_depend_on_scheduling():
     ref = None
     for _ in range(6):
         a = meshops.remove_floaters(v, f, 0.01)
-        b = meshops.reduce_faces(*a, 5000)
-        c = meshops.reduce_faces(sv, sf, 3000)
+        b = meshops.reduce_faces(*a, 5000)                 # quadric edge collapse on the marching-cubes mesh
+        c = meshops.cluster_faces(sv, sf, 3000)            # vertex clustering on the soup
         d = meshops.remove_floaters(sv, sf, 0.5)
         cur = [t.clone() for pair in (a, b, c, d) for t in pair]
         if ref is None:
