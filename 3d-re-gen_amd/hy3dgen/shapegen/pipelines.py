@@ -76,10 +76,21 @@ class Hunyuan3DDiTPipeline:
         dev = torch.device(device)
         self.cfg = cfg
         self.device = torch.device("cuda", dev.index or 0)
-        self.model = _model.ShapeModel(cfg, state_dict, self.device.index, grid_chunk=grid_chunk)
+        self.model = self._make_model(cfg, state_dict, grid_chunk)
         self.image_processor = ImageProcessorV2(**cfg["proc"])
         self.last_grid = None
         self.timings = {}
+
+    # The three places where this class touches the device.  (The API-contract test that runs the reference's stage
+    # script on a machine without a GPU overrides exactly these; the product has no CPU path.)
+    def _make_model(self, cfg, state_dict, grid_chunk):
+        return _model.ShapeModel(cfg, state_dict, self.device.index, grid_chunk=grid_chunk)
+
+    def _device_ctx(self):
+        return torch.cuda.device(self.device)
+
+    def _extract_mesh(self, grid, mc_level, box_v, octree_resolution):
+        return _mc.extract_mesh(grid, mc_level, box_v, octree_resolution)
 
     # ---- construction (same entry points as upstream) -------------------------------------------
     @classmethod
@@ -124,11 +135,13 @@ class Hunyuan3DDiTPipeline:
 
     def prepare_latents(self, generator):
         shape = (self.model.num_latents, self.model.in_channels)
-        # diffusers.randn_tensor with a CPU generator: drawn on the CPU, then moved (device independent noise);
-        # drawn in fp32 here (upstream draws in the pipeline dtype, fp16)
+        # diffusers.randn_tensor with a CPU generator: drawn on the CPU IN THE PIPELINE DTYPE (upstream: fp16), then moved --
+        # the same seed gives the same initial latents as the reference, bit for bit; the sampler then runs on their fp32
+        # image (R3G_NOISE_DTYPE=float32 restores the first round's fp32 draw)
+        dt = torch.float32 if os.environ.get("R3G_NOISE_DTYPE", "float16") == "float32" else torch.float16
         if generator is not None and generator.device.type != "cpu":
-            return torch.randn(shape, generator=generator, device=generator.device, dtype=torch.float32).to(self.device)
-        return torch.randn(shape, generator=generator, device="cpu", dtype=torch.float32).to(self.device)
+            return torch.randn(shape, generator=generator, device=generator.device, dtype=dt).float().to(self.device)
+        return torch.randn((1,) + shape, generator=generator, device="cpu", dtype=dt)[0].float().to(self.device)
 
     def generate_grid(self, image, num_inference_steps, guidance_scale, generator, box_v, octree_resolution):
         import time
@@ -154,11 +167,11 @@ class Hunyuan3DDiTPipeline:
         g = self.cfg["guidance_scale"] if guidance_scale is None else guidance_scale
         box_v = self.cfg["box_v"] if box_v is None else box_v
         mc_level = self.cfg["mc_level"] if mc_level is None else mc_level
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             grid, latents = self.generate_grid(image, num_inference_steps, g, generator, box_v, octree_resolution)
             self.last_grid = grid
             try:
-                v, f = _mc.extract_mesh(grid, mc_level, box_v, octree_resolution)
+                v, f = self._extract_mesh(grid, mc_level, box_v, octree_resolution)
             except (ValueError, RuntimeError) as e:   # upstream: traceback + None for this object
                 print("[hy3dgen] surface extraction failed: %s" % e)
                 return [None]

@@ -79,7 +79,7 @@ def conditioner_transform(image, image_size, value_range=(-1, 1)):
     x = (image.float() - low) / (high - low)
     _, _, h, w = x.shape
     s = image_size / min(h, w)
-    nh, nw = (image_size, int(round(w * s))) if h <= w else (int(round(h * s)), image_size)
+    nh, nw = (image_size, int(w * s)) if h <= w else (int(h * s), image_size)   # torchvision Resize truncates
     x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
     top, left = (nh - image_size) // 2, (nw - image_size) // 2
     x = x[:, :, top:top + image_size, left:left + image_size]

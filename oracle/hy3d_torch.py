@@ -472,7 +472,7 @@ class DinoImageEncoder(nn.Module):
         """torchvision Resize(image_size, BILINEAR, antialias=True) + CenterCrop + Normalize on [B,3,H,W] in [0,1]."""
         _, _, h, w = image.shape
         s = image_size / min(h, w)
-        nh, nw = (image_size, int(round(w * s))) if h <= w else (int(round(h * s)), image_size)
+        nh, nw = (image_size, int(w * s)) if h <= w else (int(h * s), image_size)   # torchvision Resize truncates
         x = F.interpolate(image, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
         top, left = (nh - image_size) // 2, (nw - image_size) // 2
         x = x[:, :, top:top + image_size, left:left + image_size]
@@ -540,9 +540,10 @@ def flow_sigmas(num_inference_steps, shift=1.0):
     return np.concatenate([s.astype(np.float32), np.ones(1, np.float32)])
 
 
-def prepare_latents(shape, generator):
-    """diffusers randn_tensor with a CPU generator: drawn on the CPU (here always in fp32) then moved."""
-    return torch.randn(shape, generator=generator, device="cpu", dtype=torch.float32)
+def prepare_latents(shape, generator, dtype=torch.float16):
+    """diffusers randn_tensor with a CPU generator: drawn on the CPU in the PIPELINE dtype (upstream from_pretrained
+    defaults to fp16; fp16 and fp32 draws consume the generator differently), then moved; computed on in fp32 here."""
+    return torch.randn(shape, generator=generator, device="cpu", dtype=dtype).float()
 
 
 class ShapePipeline(nn.Module):

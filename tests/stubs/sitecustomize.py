@@ -1,0 +1,23 @@
+"""Loaded automatically by the interpreter that runs the reference's stage script in tests/test_reference_script.py
+(this directory is first on its PYTHONPATH).  TEST INFRASTRUCTURE, two things:
+  * huggingface_hub.snapshot_download (reference src/2d_to_3d_models/run.py:119-120, 201-202; there is no network) is
+    replaced by a function that returns the local synthetic snapshot directory named by R3G_TEST_SNAPSHOT;
+  * R3G_TEST_CPU_SHIM=1 installs the CPU compute stand-ins of tests/ref_shim.py, which let the UNMODIFIED reference
+    script run against the hy3dgen mirror's API on a machine without a GPU (the product itself has no CPU path)."""
+import os
+import sys
+
+if os.environ.get("R3G_TEST_SNAPSHOT"):
+    import huggingface_hub
+
+    def _snapshot_download(repo_id=None, **kwargs):
+        path = os.environ["R3G_TEST_SNAPSHOT"]
+        print("[test stub] snapshot_download(%r) -> %s" % (repo_id, path))
+        return path
+    huggingface_hub.snapshot_download = _snapshot_download
+
+if os.environ.get("R3G_TEST_CPU_SHIM") == "1":
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import ref_shim
+    ref_shim.install()

@@ -41,7 +41,7 @@ def test_contract_at_the_reference_grid_size():
     from r3g import meshops
     from parity_support import report
     v, f = _mc(_blob(257, 3))
-    assert f.shape[0] > 150000
+    assert f.shape[0] > 100000
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     gv, gf = meshops.reduce_faces(v, f, 40000)
