@@ -15,6 +15,7 @@ struct McWorkspaceLayout {
     uint64_t off_blk, off_blkoff, off_nz, off_act, off_etab;
 };
 
+void mc_set_deferred(bool on);         // row kernel: tiling selection batched per wave (default) or per row
 void mc_set_rows_per_wave(int rows);  // node rows a wave marches through in the row kernel (4|8|16|32)
 size_t mc_workspace_bytes(int n0, int n1, int n2, McWorkspaceLayout* lay);
 

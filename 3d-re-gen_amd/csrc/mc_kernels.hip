@@ -8,11 +8,16 @@
 // Launch structure (cells are linearised in scan order, axis 2 fastest; 256 cells per block):
 //   K1 classify    : sign field -> tiling (fp64 ambiguity tests only in active lanes) -> per-block
 //                    compacted records {tiling, counts, in-block prefix}, block sums, chunk sums.
-//       mc_classify_rows (row length % 256 == 0, e.g. the 257^3 grid): one WAVE per 256-cell block, 4 cells
-//                    per lane, marching 16 rows along axis 1 so that every node row is loaded once per wave
-//                    as dwordx4 + dword, next rows in flight while the current ones are tested (float-domain
-//                    sign test).  The few active cells of a row are packed into consecutive lanes through
-//                    LDS before the tiling selection; the in-block scan is a wave64 shuffle scan (no barrier).
+//       mc_classify_rows2 (row length % 256 == 0, e.g. the 257^3 grid; default): one WAVE per 256-cell block, 4
+//                    cells per lane, marching 16 rows along axis 1 so that every node row is loaded once per wave
+//                    as dwordx4 + dword, next rows in flight while the current ones are tested.  The sign test is
+//                    v_cmp into wave-wide SGPR masks and the "does this cell straddle the level" logic is 64-bit
+//                    scalar arithmetic on them (~30 VALU + ~65 SALU instructions per 256-cell row); active cells
+//                    are appended to a per-wave list in LDS and the long tiling selection runs once over the list
+//                    with all lanes busy; in-row prefix sums by a segmented wave scan; ONE pair of chunk-total
+//                    atomics per wave.  Workgroups are numbered so that each XCD owns a slab of z.
+//       mc_classify_rows  (option mc_deferred=0): round 1's variant, per-lane bit masks and the tiling selection
+//                    per row; kept as the cross-check (same outputs bit for bit).
 //       mc_classify      (any other shape): one thread per cell, 8 coalesced row reads, LDS across 4 waves.
 //   K2 mc_scan     : exclusive scan of the block sums (one workgroup per 1024-block chunk) + the
 //                    compacted list of non-empty blocks.
@@ -132,6 +137,13 @@ __global__ __launch_bounds__(kBlock) void mc_classify(const float* __restrict__ 
 }
 
 // ---- row kernel ------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Every node slice is read twice (as the lower
+// and as the upper face of a cell layer): giving each XCD a contiguous range of task numbers (= a slab of z) makes the
+// second read an L2 hit instead of a second trip over the fabric.
+__device__ __forceinline__ uint32_t xcd_slab_block(uint32_t bid, uint32_t nb) {
+    const uint32_t xcd = bid & 7u, local = bid >> 3, q = nb >> 3, r = nb & 7u;
+    return xcd * q + min(xcd, r) + local;
+}
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // node rows of a 257-wide grid are only 4-B aligned
 
 struct Row5 { f4u a; float e; };  // the 5 nodes above a lane's 4 cells
@@ -163,7 +175,7 @@ void mc_classify_rows(const float* __restrict__ grid, int nx, int ny, int cx, in
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t segs = (uint32_t)cx >> 8;                       // 256-cell blocks per row
     const uint32_t ychunks = ((uint32_t)cy + kRowsPerWave - 1) / kRowsPerWave;
-    const uint32_t task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);  // wave-uniform
+    const uint32_t task = xcd_slab_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);  // wave-uniform
     if (task >= segs * ychunks * (uint32_t)cz) return;
     const uint32_t seg = task % segs, t2 = task / segs;
     const int z = (int)(t2 / ychunks), y0 = (int)(t2 % ychunks) * kRowsPerWave;
@@ -172,6 +184,9 @@ void mc_classify_rows(const float* __restrict__ grid, int nx, int ny, int cx, in
     const int64_t sz = (int64_t)nx * ny;
     const float* p = grid + (int64_t)z * sz + (int64_t)y0 * nx + xb;
     unsigned flags = 0;
+    uint32_t acc_chunk = 0xFFFFFFFFu;
+    unsigned long long acc_sum = 0;
+    unsigned acc_nz = 0;
     unsigned m0, m1;
     {
         const Row5 r0 = row_load(p), r1 = row_load(p + sz);
@@ -249,15 +264,219 @@ void mc_classify_rows(const float* __restrict__ grid, int nx, int ny, int cx, in
                 const unsigned sa = (unsigned)((incl >> 32) & 0xFFFFu);
                 if (sa) {
                     blk[b] = make_uint4(sv, st, sa, 0u);
-                    if (sv | st)
-                        atomicAdd(&chunk_sums[b / kChunk], (unsigned long long)sv | ((unsigned long long)st << 32));
-                    atomicAdd(&chunk_nz[b / kChunk], 1u);
+                    // chunk totals: one atomic pair per wave and chunk, not per row (the ~60 chunk counters of a 257^3
+                    // grid otherwise take ~50k same-address atomics)
+                    if (acc_chunk != b / kChunk) {
+                        if (acc_nz) {
+                            if (acc_sum) atomicAdd(&chunk_sums[acc_chunk], acc_sum);
+                            atomicAdd(&chunk_nz[acc_chunk], acc_nz);
+                        }
+                        acc_chunk = b / kChunk; acc_sum = 0; acc_nz = 0;
+                    }
+                    acc_sum += (unsigned long long)sv | ((unsigned long long)st << 32);
+                    acc_nz += 1u;
                 }
             }
         }
         m0 = n0; m1 = n1;
         q0 = f0; q1 = f1;
         p += nx;
+    }
+    if (acc_nz) {   // lane 63 only
+        if (acc_sum) atomicAdd(&chunk_sums[acc_chunk], acc_sum);
+        atomicAdd(&chunk_nz[acc_chunk], acc_nz);
+    }
+    const unsigned long long le = __ballot(flags & R3G_MC_FLAG_LE), ge = __ballot(flags & R3G_MC_FLAG_GE),
+                             nn = __ballot(flags & R3G_MC_FLAG_NAN);
+    const unsigned wf = (le ? R3G_MC_FLAG_LE : 0u) | (ge ? R3G_MC_FLAG_GE : 0u) | (nn ? R3G_MC_FLAG_NAN : 0u);
+    if (lane == 0 && (wf & ~*(volatile unsigned*)status)) atomicOr(status, wf);
+}
+
+// ---- row kernel, second version: the tiling selection is DEFERRED.  While a wave streams its node rows it only appends
+// the cells that straddle the level to a list in LDS (position inside the 256-cell row block + row number); the long,
+// latency-bound selection code (fp64 ambiguity tests, chains of dependent table loads) then runs ONCE over the whole
+// list, 64 cells at a time, instead of once per row with one or two busy lanes -- a smooth surface crosses ~40 % of
+// the rows of a 257^3 grid but activates only ~20 cells per 16 rows.  Records, in-row prefix sums and block totals are
+// produced by a segmented wave scan over the list (rows are contiguous in it).  Same outputs as mc_classify_rows.
+constexpr int kListCap = 1024;   // entries per wave; a row adds at most 256
+
+template <int kRowsPerWave>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void mc_classify_rows2(const float* __restrict__ grid, int nx, int ny, int cx, int cy, int cz, float lo, int lo_exact,
+                       double level, int classic, uint2* __restrict__ act, uint4* __restrict__ blk,
+                       unsigned long long* __restrict__ chunk_sums, unsigned* __restrict__ chunk_nz,
+                       unsigned* __restrict__ status) {
+    __shared__ unsigned short s_cell[kBlock / 64][kListCap];          // (row - y0) << 8 | cell
+    __shared__ unsigned s_rec[kBlock / 64][kListCap];
+    __shared__ unsigned long long s_rowbase[kBlock / 64][kRowsPerWave + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t segs = (uint32_t)cx >> 8;
+    const uint32_t ychunks = ((uint32_t)cy + kRowsPerWave - 1) / kRowsPerWave;
+    const uint32_t task = xcd_slab_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (task >= segs * ychunks * (uint32_t)cz) return;
+    const uint32_t seg = task % segs, t2 = task / segs;
+    const int z = (int)(t2 / ychunks), y0 = (int)(t2 % ychunks) * kRowsPerWave;
+    const int y1 = min(cy, y0 + kRowsPerWave);
+    const int xb = (int)seg * 256 + lane * 4;
+    const int64_t sz = (int64_t)nx * ny;
+    const float* p = grid + (int64_t)z * sz + (int64_t)y0 * nx + xb;
+    unsigned flags = 0;
+    unsigned n_list = 0;   // wave-uniform
+    uint32_t acc_chunk = 0xFFFFFFFFu;   // per-lane partial chunk totals, reduced to one atomic pair per wave at the end
+    unsigned long long acc_sum = 0;
+    unsigned acc_nz = 0;
+
+    auto flush = [&]() {
+        if (n_list == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 1. tiling selection for every listed cell, 64 at a time
+        for (unsigned i = lane; i < n_list; i += 64) {
+            const unsigned e = s_cell[wid][i];
+            const int x = (int)seg * 256 + (int)(e & 0xFFu), y = y0 + (int)(e >> 8);
+            double v[8];
+            int index;
+            load_corners(grid, nx, ny, x, y, z, level, v, &index);
+            s_rec[wid][i] = classify_cell(v, index, classic != 0, x, y, z);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 2. segmented exclusive scan (segments = rows): packed counters [0..15] vertices, [16..31] triangles, [32..47] cells
+        unsigned long long carry = 0;
+        for (unsigned base = 0; base < n_list; base += 64) {
+            const unsigned i = base + lane;
+            const bool in = i < n_list;
+            const unsigned rec = in ? s_rec[wid][i] : 0u;
+            const unsigned row = in ? (unsigned)(s_cell[wid][i] >> 8) : 0xFFFFu;
+            const unsigned long long mine = (unsigned long long)((rec >> 20) & 0xFu) |
+                                            ((unsigned long long)((rec >> 16) & 0xFu) << 16) |
+                                            ((unsigned long long)(rec ? 1u : 0u) << 32);
+            const unsigned long long incl = wave_inclusive_scan(mine, lane) + carry;
+            const unsigned long long gex = incl - mine;
+            // the first entry of a row publishes the running total at the row's start
+            const bool head = in && (i == 0 || (unsigned)(s_cell[wid][i - 1] >> 8) != row);
+            if (head) s_rowbase[wid][row] = gex;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (in) {
+                const unsigned long long excl = gex - s_rowbase[wid][row];
+                const uint32_t b = ((uint32_t)z * (uint32_t)cy + (uint32_t)(y0 + (int)row)) * segs + seg;
+                if (rec) {
+                    const unsigned vloc = (unsigned)(excl & 0xFFFFu), tloc = (unsigned)((excl >> 16) & 0xFFFFu);
+                    const unsigned arank = (unsigned)((excl >> 32) & 0xFFFFu);
+                    act[(size_t)b * kBlock + arank] =
+                        make_uint2(rec, (unsigned)(s_cell[wid][i] & 0xFFu) | (vloc << 8) | (tloc << 20));
+                }
+                const bool last = i + 1 == n_list || (unsigned)(s_cell[wid][i + 1] >> 8) != row;
+                if (last) {
+                    const unsigned long long tot = excl + mine;
+                    const unsigned sv = (unsigned)(tot & 0xFFFFu), st = (unsigned)((tot >> 16) & 0xFFFFu);
+                    const unsigned sa = (unsigned)((tot >> 32) & 0xFFFFu);
+                    if (sa) {
+                        blk[b] = make_uint4(sv, st, sa, 0u);
+                        if (acc_nz && acc_chunk != b / kChunk) {
+                            if (acc_sum) atomicAdd(&chunk_sums[acc_chunk], acc_sum);
+                            atomicAdd(&chunk_nz[acc_chunk], acc_nz);
+                            acc_sum = 0; acc_nz = 0;
+                        }
+                        acc_chunk = b / kChunk;
+                        acc_sum += (unsigned long long)sv | ((unsigned long long)st << 32);
+                        acc_nz += 1u;
+                    }
+                }
+            }
+            carry = __shfl(incl, 63, 64);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        n_list = 0;
+    };
+
+    // Streaming part.  A node row is turned into five wave-wide masks (one per node of a lane's 4-cell group: bit L of
+    // G[k] <=> node 4L+k > level) by v_cmp into SGPR pairs; everything that decides whether a cell straddles the level
+    // is then 64-bit SCALAR arithmetic on those masks, shared by the rows above / below and the two slices -- about
+    // 30 vector and 40 scalar instructions per row of 256 cells.  (The per-lane bit-twiddling this replaces took ~200
+    // vector instructions per row and made the kernel VALU-bound at 1.4 TB/s.)
+    float vmin = __builtin_inff(), vmax = -__builtin_inff();   // range flags: min / max per lane, NaNs by v_cmp_u
+    unsigned long long nan_mask = 0;
+    struct RowMasks { unsigned long long o[4], a[4]; };       // per cell column c: OR / AND over nodes c, c+1 of both slices
+    auto masks_of = [&](const Row5& r0, const Row5& r1) -> RowMasks {
+        vmax = fmaxf(fmaxf(vmax, fmaxf(r0.a.x, r0.a.y)), fmaxf(fmaxf(r0.a.z, r0.a.w), r0.e));
+        vmax = fmaxf(fmaxf(vmax, fmaxf(r1.a.x, r1.a.y)), fmaxf(fmaxf(r1.a.z, r1.a.w), r1.e));
+        vmin = fminf(fminf(vmin, fminf(r0.a.x, r0.a.y)), fminf(fminf(r0.a.z, r0.a.w), r0.e));
+        vmin = fminf(fminf(vmin, fminf(r1.a.x, r1.a.y)), fminf(fminf(r1.a.z, r1.a.w), r1.e));
+        nan_mask |= __ballot(__builtin_isunordered(r0.a.x, r0.a.y)) | __ballot(__builtin_isunordered(r0.a.z, r0.a.w)) |
+                    __ballot(__builtin_isunordered(r1.a.x, r1.a.y)) | __ballot(__builtin_isunordered(r1.a.z, r1.a.w)) |
+                    __ballot(__builtin_isunordered(r0.e, r1.e));
+        const unsigned long long g0[5] = {__ballot(r0.a.x > lo), __ballot(r0.a.y > lo), __ballot(r0.a.z > lo),
+                                          __ballot(r0.a.w > lo), __ballot(r0.e > lo)};
+        const unsigned long long g1[5] = {__ballot(r1.a.x > lo), __ballot(r1.a.y > lo), __ballot(r1.a.z > lo),
+                                          __ballot(r1.a.w > lo), __ballot(r1.e > lo)};
+        RowMasks m;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            m.o[c] = g0[c] | g0[c + 1] | g1[c] | g1[c + 1];
+            m.a[c] = g0[c] & g0[c + 1] & g1[c] & g1[c + 1];
+        }
+        return m;
+    };
+    RowMasks mp = masks_of(row_load(p), row_load(p + sz));
+    Row5 q0 = row_load(p + nx), q1 = row_load(p + sz + nx);
+    for (int y = y0; y < y1; ++y) {
+        Row5 f0 = q0, f1 = q1;
+        if (y + 1 < y1) {   // rows y+2 go in flight before rows y+1 are consumed
+            f0 = row_load(p + 2 * (int64_t)nx);
+            f1 = row_load(p + sz + 2 * (int64_t)nx);
+        }
+        const RowMasks mn = masks_of(q0, q1);
+        unsigned long long actm[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) actm[c] = (mp.o[c] | mn.o[c]) & ~(mp.a[c] & mn.a[c]);
+        if ((actm[0] | actm[1] | actm[2] | actm[3]) != 0ull) {
+            const unsigned n_active = (unsigned)(__popcll(actm[0]) + __popcll(actm[1]) + __popcll(actm[2]) + __popcll(actm[3]));
+            if (n_list + n_active > (unsigned)kListCap) flush();
+            // list position of a lane's first active cell: active cells in the lanes below (cells are ordered by x)
+            unsigned slot = n_list;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                slot += __builtin_amdgcn_mbcnt_hi((unsigned)(actm[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)actm[c], 0u));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((actm[c] >> lane) & 1ull) s_cell[wid][slot++] = (unsigned short)(((unsigned)(y - y0) << 8) | (unsigned)(lane * 4 + c));
+            n_list += n_active;
+        }
+        mp = mn;
+        q0 = f0; q1 = f1;
+        p += nx;
+    }
+    {
+        if (vmin <= lo) flags |= R3G_MC_FLAG_LE;
+        if (vmax > lo || (lo_exact && vmax == lo)) flags |= R3G_MC_FLAG_GE;
+        if (nan_mask) flags |= R3G_MC_FLAG_NAN;
+    }
+    flush();
+    {
+        // all rows of a wave normally fall into one chunk: reduce over the wave, one lane adds
+        const unsigned long long have = __ballot(acc_nz != 0u);
+        if (have) {
+            const uint32_t c0 = (uint32_t)__shfl((int)acc_chunk, __ffsll((long long)have) - 1, 64);
+            if (__all(acc_nz == 0u || acc_chunk == c0)) {
+                unsigned long long ts = acc_sum;
+                unsigned tn = acc_nz;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    ts += (unsigned long long)__shfl_xor((long long)ts, d, 64);
+                    tn += (unsigned)__shfl_xor((int)tn, d, 64);
+                }
+                if (lane == 0) {
+                    if (ts) atomicAdd(&chunk_sums[c0], ts);
+                    atomicAdd(&chunk_nz[c0], tn);
+                }
+            } else if (acc_nz) {
+                if (acc_sum) atomicAdd(&chunk_sums[acc_chunk], acc_sum);
+                atomicAdd(&chunk_nz[acc_chunk], acc_nz);
+            }
+        }
     }
     const unsigned long long le = __ballot(flags & R3G_MC_FLAG_LE), ge = __ballot(flags & R3G_MC_FLAG_GE),
                              nn = __ballot(flags & R3G_MC_FLAG_NAN);
@@ -371,6 +590,8 @@ __global__ __launch_bounds__(kEmitThreads) void mc_faces(int nx, int ny, int cx,
 namespace r3g {
 
 static int g_rows_per_wave = 16;
+static bool g_deferred = true;   // row kernel with the tiling selection batched over all rows of a wave
+void mc_set_deferred(bool on) { g_deferred = on; }
 void mc_set_rows_per_wave(int rows) { g_rows_per_wave = rows == 4 || rows == 8 || rows == 32 ? rows : 16; }
 
 size_t mc_workspace_bytes(int n0, int n1, int n2, McWorkspaceLayout* lay) {
@@ -417,6 +638,10 @@ hipError_t mc_count_launch(const float* grid, int n0, int n1, int n2, double lev
         const uint32_t tasks = (uint32_t)(cx / kBlock) * (uint32_t)((cy + rows - 1) / rows) * (uint32_t)cz;
         auto kern = rows == 4 ? mc_classify_rows<4> : rows == 8 ? mc_classify_rows<8> : rows == 32 ? mc_classify_rows<32>
                                                                                                 : mc_classify_rows<16>;
+        if (g_deferred) {
+            kern = rows == 4 ? mc_classify_rows2<4> : rows == 8 ? mc_classify_rows2<8> : rows == 32 ? mc_classify_rows2<32>
+                                                                                                   : mc_classify_rows2<16>;
+        }
         hipLaunchKernelGGL(kern, dim3((tasks + 3) / 4), dim3(kBlock), 0, stream, grid, nx, ny, cx, cy, cz,
                            lo, exact, level, classic, (uint2*)(ws + lay.off_act), (uint4*)(ws + lay.off_blk),
                            chunk_sums, chunk_nz, status);
