@@ -97,10 +97,14 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 // Epilogue shared by all GEMM kernels.  acc[j][i]: wave-local sub-tile (n group j of 16 columns, m group i of 16 rows);
 // lane holds row m = m0 + wr*WROWS + i*16 + (lane&15), columns n0 + wc*64 + j*16 + (lane>>4)*4 + {0..3}.
 // lds_wave: wave-private LDS scratch of WROWS x 128 bytes (free once the k-loop's last barrier has passed), or null.
-template <int EPI, int MI, bool SMALLREG>
+// PI: 16-row groups per pass through the scratch (PI * 16 rows x 128 bytes of LDS per wave; PI = MI: one pass).
+// VM0: s_waitcnt vmcnt(0) before the first global store (the persistent kernel issues the next tile's LDS-DMA before this
+// epilogue and wants it landed, but must not wait for the epilogue's own stores afterwards).
+template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
                                               int wc, int lane, char* lds_wave = nullptr) {
     constexpr int WROWS = MI * 16;
+    static_assert(MI % PI == 0 && (EPI != EPI_QKV || PI == MI), "scratch passes");
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
         // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
@@ -303,44 +307,51 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             const int cc = lane & 7;
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
+                f32x4 bj[2], gj[2];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const int j = 2 * jp + jj;
-                    const int nb = ncol + j * 16;
+                    const int nb = ncol + (2 * jp + jj) * 16;
                     const int nbc = nb < p.N ? nb : p.N - 4;
-                    f32x4 bj = (f32x4){0.f, 0.f, 0.f, 0.f}, gj = (f32x4){1.f, 1.f, 1.f, 1.f};
-                    if (p.bias) bj = *reinterpret_cast<const f32x4*>(p.bias + nbc);
-                    if (gate) gj = *reinterpret_cast<const f32x4*>(gate + nbc);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int r = i * 16 + (lane & 15);
-                        const int chunk = (jj * 4 + (lane >> 4)) ^ (r & 7);
-                        *reinterpret_cast<f32x4*>(lds_wave + r * 128 + chunk * 16) = gj * (acc[j][i] + bj);
-                    }
+                    bj[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    gj[jj] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                    if (p.bias) bj[jj] = *reinterpret_cast<const f32x4*>(p.bias + nbc);
+                    if (gate) gj[jj] = *reinterpret_cast<const f32x4*>(gate + nbc);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
                 const int n = n0 + wc * 64 + jp * 32 + cc * 4;
                 const int nc = n < p.N ? n : p.N - 4;
 #pragma unroll
-                for (int t0 = 0; t0 < WROWS / 8; t0 += 4) {
-                    f32x4 old[4];
+                for (int ip = 0; ip < MI; ip += PI) {
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int m = m0 + wr * WROWS + (t0 + tt) * 8 + (lane >> 3);
-                        const int mc = m < p.M ? m : p.M - 1;
-                        old[tt] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
-                    }
+                    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int rr = (t0 + tt) * 8 + (lane >> 3);
-                        const int m = m0 + wr * WROWS + rr;
-                        const f32x4 d = *reinterpret_cast<const f32x4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
-                        if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = old[tt] + d;
+                        for (int ii = 0; ii < PI; ++ii) {
+                            const int r = ii * 16 + (lane & 15);
+                            const int chunk = (jj * 4 + (lane >> 4)) ^ (r & 7);
+                            *reinterpret_cast<f32x4*>(lds_wave + r * 128 + chunk * 16) = gj[jj] * (acc[2 * jp + jj][ip + ii] + bj[jj]);
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (VM0 && jp == 0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int t0 = 0; t0 < PI * 2; t0 += 4) {
+                        f32x4 old[4];
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const int m = m0 + wr * WROWS + ip * 16 + (t0 + tt) * 8 + (lane >> 3);
+                            const int mc = m < p.M ? m : p.M - 1;
+                            old[tt] = *reinterpret_cast<const f32x4*>(X + (int64_t)mc * p.ldc + nc);
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const int rr = (t0 + tt) * 8 + (lane >> 3);
+                            const int m = m0 + wr * WROWS + ip * 16 + rr;
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                            if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = old[tt] + d;
+                        }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
             return;
         }
@@ -357,7 +368,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     }
     const int64_t cbase = (int64_t)batch * p.strideC;
     if constexpr (EPI == EPI_RESID_F32) {
-        float* X = reinterpret_cast<float*>(p.C) + cbase;
+        float* X = reinterpret_cast<float*>(p.C) + cbase;   // (VM0: the loads of the old values are the wait)
         // 16-wave tiles run at a 128-VGPR budget: read-modify-write one column group at a time there
         constexpr int JG = SMALLREG ? 1 : 4;
 #pragma unroll
@@ -386,49 +397,59 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         // instruction then writes 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 32 bytes
         const bool wide = EPI != EPI_F32 && lds_wave != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
                           (p.strideC & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+        if (VM0 && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ip = 0; ip < MI; ip += PI) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int n = ncol + j * 16, m = mrow + i * 16;
-                f32x4 v = acc[j][i] + biasv[j];
-                if (EPI == EPI_BF16_GELU_TANH) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                } else if (EPI == EPI_BF16_GELU_ERF) {
+                for (int ii = 0; ii < PI; ++ii) {
+                    const int i = ip + ii;
+                    const int n = ncol + j * 16, m = mrow + i * 16;
+                    f32x4 v = acc[j][i] + biasv[j];
+                    if (EPI == EPI_BF16_GELU_TANH) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                }
-                if (EPI != EPI_F32 && wide) {
-                    uint2 pk;
-                    pk.x = pack_bf16(v[0], v[1]);
-                    pk.y = pack_bf16(v[2], v[3]);
-                    const int r = i * 16 + (lane & 15), q = lane >> 4;
-                    const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
-                    *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
-                } else if (n < p.N && m < p.M) {
-                    const int64_t off = cbase + (int64_t)m * p.ldc + n;
-                    if (EPI == EPI_F32) {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
-                    } else {
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    } else if (EPI == EPI_BF16_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if (EPI != EPI_F32 && wide) {
                         uint2 pk;
                         pk.x = pack_bf16(v[0], v[1]);
                         pk.y = pack_bf16(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                        const int r = ii * 16 + (lane & 15), q = lane >> 4;
+                        const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
+                        *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
+                    } else if (n < p.N && m < p.M) {
+                        const int64_t off = cbase + (int64_t)m * p.ldc + n;
+                        if (EPI == EPI_F32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                        } else {
+                            uint2 pk;
+                            pk.x = pack_bf16(v[0], v[1]);
+                            pk.y = pack_bf16(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                        }
                     }
                 }
-            }
-        if (EPI != EPI_F32 && wide) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
-            const int cc = lane & 7, n = n0 + wc * 64 + cc * 8;
+            if (EPI != EPI_F32 && wide) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
+                const int cc = lane & 7, n = n0 + wc * 64 + cc * 8;
+                if (VM0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int t = 0; t < WROWS / 8; ++t) {
-                const int rr = t * 8 + (lane >> 3);
-                const int m = m0 + wr * WROWS + rr;
-                const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
-                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
+                for (int t = 0; t < PI * 2; ++t) {
+                    const int rr = t * 8 + (lane >> 3);
+                    const int m = m0 + wr * WROWS + ip * 16 + rr;
+                    const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
+                }
+                if (PI != MI) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     }
@@ -868,6 +889,261 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
     gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form of the phased kernel: the grid is one workgroup per CU (balanced over the dispatch rounds) and every
+// workgroup walks tiles w, w + G, w + 2G, ...  Between two tiles it issues the LDS-DMA of the NEXT tile's first k-tile,
+// runs the epilogue of the tile it just finished out of a separate 32 KiB of LDS scratch (4 KiB per wave, 32 rows per
+// pass), issues the second k-tile and enters the k-loop with the usual counted wait (vmcnt(6): everything older than
+// the six newest pieces, so it is exact whatever the epilogue issued).  The prologue latency hides under the epilogue and
+// there is no workgroup dispatch between tiles.  s_memtime stamps (profiles/r02_gemm_persistent.md): at K = 1024 a tile
+// is k-loop 37 k cycles (93 % of the MFMA issue rate) + epilogue 15-26 k + prologue 6 k in the one-tile-per-workgroup
+// kernel; this form removes most of the prologue and part of the epilogue wait (bf16 outputs -2 .. -9 %).  The fp32
+// read-modify-write epilogue is bound by HBM (1.3 GB per launch at ~3.5 TB/s) and stays on gemm8_kernel.
+// Same k-order and MFMA shape as gemm8_kernel: bit-identical results.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, MI = 8;
+    constexpr int HALF = 16384, BUF = 4 * HALF;   // buffer: [A_0][A_1][W_0][W_1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg_first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
+    typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kSecond = (sizeof(GemmArgs) + alignof(GemmArgs) - 1) / alignof(GemmArgs) * alignof(GemmArgs);
+    (void)pb;
+    const int wr = wid >> 2, wc = wid & 3;
+
+    struct Tile { int second, batch, m0, n0; };
+    auto args_of = [&](int second) -> const GemmArgs& {
+        return *(const GemmArgs*)(const GemmArgs __attribute__((address_space(4)))*)(ka + (second ? kSecond : 0));
+    };
+    auto locate = [&](int wg_all) -> Tile {
+        Tile t;
+        t.second = wg_all >= tiles_a ? 1 : 0;
+        const GemmArgs& p = args_of(t.second);
+        const int wg = t.second ? wg_all - tiles_a : wg_all;
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        const int rg = p.raster_group < 0 ? 4 : p.raster_group;
+        const int GN = rg > 0 ? rg : tiles_n;
+        const int rows_all = tiles_m * p.batch;
+        const int per_group = rows_all * GN;
+        const int group = wg / per_group;
+        const int within = wg - group * per_group;
+        const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+        const int rowi = within / gn_cur;
+        const int tn = group * GN + (within - rowi * gn_cur);
+        t.batch = rowi / tiles_m;
+        t.m0 = (rowi - t.batch * tiles_m) * BM;
+        t.n0 = tn * BN;
+        return t;
+    };
+
+    const uint16_t* srcA[2][2];
+    const uint16_t* srcW[2][2];
+    auto set_sources = [&](const Tile& tl) {
+        const GemmArgs& p = args_of(tl.second);
+        const uint16_t* A = p.A + (int64_t)tl.batch * p.strideA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wid * 2 + i) * 8 + (lane >> 3);        // row inside the half-tile
+            const int kc = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int ga = tl.m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+                int gw = tl.n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+                ga = ga < p.M ? ga : p.M - 1;
+                gw = gw < p.N ? gw : p.N - 1;
+                srcA[h][i] = A + (int64_t)ga * p.lda + kc * 8;
+                srcW[h][i] = p.W + (int64_t)gw * p.ldw + kc * 8;
+            }
+        }
+    };
+    char* const dst0 = smem + wid * 2048;   // + buffer * BUF + region * HALF + i * 1024
+    auto stage_a = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[h][i] + (int64_t)t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + h * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+    auto stage_w = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[h][i] + (int64_t)t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + (2 + h) * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+    const int sw = (lane >> 1) & 7;
+    int offA[2], offW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        offA[kk] = (wr * 64 + (lane & 15)) * 128 + ((((kk << 2) + (lane >> 4)) ^ sw) << 4);
+        offW[kk] = (wc * 32 + (lane & 15)) * 128 + ((((kk << 2) + (lane >> 4)) ^ sw) << 4);
+    }
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], wf0[2][2], wf1[2][2];
+    auto read_a = [&](int h, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                af[i][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + h * HALF + i * 2048 + offA[kk]);
+    };
+    auto read_w0 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                wf0[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + 2 * HALF + j * 2048 + offW[kk]);
+    };
+    auto read_w1 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                wf1[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + 3 * HALF + j * 2048 + offW[kk]);
+    };
+    auto mma = [&](auto HA, auto HW) {
+        constexpr int ha = decltype(HA)::value, hw = decltype(HW)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[hw * 2 + j][ha * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        hw ? wf1[j][kk] : wf0[j][kk], af[i][kk], acc[hw * 2 + j][ha * 4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // LAST: the tile's last pair of k-tiles, nothing left to stage
+    auto four_phases = [&](auto B, auto LAST, const int t) {
+        constexpr int b = decltype(B)::value;
+        constexpr bool last = decltype(LAST)::value;
+        read_w0(b);
+        R3G_SB();
+        read_a(0, b);
+        R3G_SB();
+        if (!last || b == 0) stage_a(1, t + 1, b ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+        read_w1(b);
+        R3G_SB();
+        if (!last) stage_w(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        read_a(1, b);
+        R3G_SB();
+        if (!last) stage_a(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        if (!last) {
+            stage_w(1, t + 2, b);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (b == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A_1 of the last k-tile
+        }
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    auto locate_u = [&](int index, Tile& tl, int& nk) {
+        tl = locate(index);
+        tl.second = __builtin_amdgcn_readfirstlane(tl.second);
+        tl.batch = __builtin_amdgcn_readfirstlane(tl.batch);
+        tl.m0 = __builtin_amdgcn_readfirstlane(tl.m0);
+        tl.n0 = __builtin_amdgcn_readfirstlane(tl.n0);
+        nk = args_of(tl.second).K / BK;   // even, >= 4 (checked by the launcher)
+    };
+    Tile cur;
+    int nk;
+    int my = wg_first;            // < total_tiles: the grid is never larger than the tile count
+    locate_u(my, cur, nk);
+    set_sources(cur);
+    stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+    for (;;) {
+        // k-tile 0 is on its way (and, after the first tile, the previous tile's stores); k-tile 1 follows as in gemm8_kernel.
+        // vmcnt(6) retires everything older than these six pieces -- exact whatever the epilogue issued.
+        stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        R3G_BAR();
+        if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
+        int t = 0;
+        for (; t + 2 < nk; t += 2) {
+            four_phases(I0{}, F{}, t);
+            four_phases(I1{}, F{}, t + 1);
+        }
+        four_phases(I0{}, T{}, t);
+        four_phases(I1{}, T{}, t + 1);
+        if (wr == 0) R3G_BAR();
+
+        const Tile done = cur;
+        my += nwg;
+        const bool more = my < total_tiles;
+        if (more) {
+            // the next tile's first k-tile goes out before the epilogue and lands under it
+            locate_u(my, cur, nk);
+            set_sources(cur);
+            stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+        }
+        {
+            const GemmArgs& pp = args_of(done.second);
+            gemm_epilogue<EPI, MI, true, 2>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane,
+                                            pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr);
+        }
+        if (!more) break;
+        // the staging pointers are recomputed rather than kept alive across the epilogue (16 registers it needs); the
+        // empty asm keeps the compiler from merging the two computations
+        asm volatile("" : "+s"(cur.m0), "+s"(cur.n0), "+s"(cur.batch));
+        set_sources(cur);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int EPI>
+hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipStream_t s) {
+    int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+    if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+    const int rounds = (tiles + num_cu - 1) / num_cu;
+    const int grid = (tiles + rounds - 1) / rounds;    // every workgroup gets `rounds` tiles (the last ones one fewer)
+    const size_t lds = 163840;
+    auto k = gemm8p_kernel<EPI>;
+    static int state = 0;   // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS
+    if (state == 0)
+        state = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+    if (state < 0) { (void)hipGetLastError(); return hipErrorNotSupported; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles);
+    return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_gemm8(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
     int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
@@ -924,6 +1200,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 1, g_num_cu = 256;
+bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
 
@@ -951,8 +1228,21 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             else waves = 8;
         }
     }
-    if (waves == 11 && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) return launch_gemm8<EPI>(p, p2, s);   // phased 256x256x64
-    if (waves == 11) waves = g_gemm_waves == 0 ? 9 : 8;
+    if ((waves == 11 || waves == 12) && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) {   // phased 256x256x64
+        if constexpr (EPI != EPI_QKV) {
+            // persistent form when a CU gets more than one tile and the output is bf16 (waves == 12 forces it for any
+            // epilogue but QKV); it needs 160 KiB of LDS per workgroup
+            long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+            if (p2.M > 0) tiles += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+            if (p.K >= 256 && (p2.M == 0 || p2.K >= 256) &&
+                (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && EPI != EPI_RESID_F32 && EPI != EPI_F32))) {
+                const hipError_t e = launch_gemm8p<EPI>(p, p2, g_num_cu, s);
+                if (e != hipErrorNotSupported) return e;
+            }
+        }
+        return launch_gemm8<EPI>(p, p2, s);
+    }
+    if (waves == 11 || waves == 12) waves = g_gemm_waves == 0 ? 9 : 8;
     if (waves == 32 && p.K % 32 == 0 && p2.M == 0) return launch_deep<EPI>(p, batch, s);   // deep-ring 256x256x32 kernel
     if (waves == 16) return launch_cfg<EPI, 16, 1>(p, p2, glds, s);
     if (waves == 9) return launch_cfg<EPI, 8, 1>(p, p2, glds, s);   // 256x256 tile, 8 waves of 128x64
@@ -972,8 +1262,9 @@ void gemm_set_auto_rule(int rule, int num_cu) {
 }
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_phased(bool on) { g_gemm_phased = on; }
+void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 

@@ -27,6 +27,8 @@ SHAPES = {
             (7552, 1024, 1024, 3), (7552, 7168, 1024, 0)],
     # ... and of one 131072-point pass of the geo decoder
     "geo": [(131072, 1024, 1024, 0), (131072, 1024, 1024, 3), (131072, 4096, 1024, 2), (131072, 1024, 4096, 3)],
+    # K sweep at the geo decoder's M: intercept = fixed cost per tile round (prologue + epilogue), slope = cost per k
+    "ksweep": [(131072, 1024, k, e) for e in (0, 3) for k in (128, 256, 512, 1024, 2048)],
     # ragged edges for the screen
     "edge": [(300, 256, 128, 0), (77, 512, 256, 3), (1371, 1024, 1024, 1), (515, 768, 1024, 3), (4442, 1024, 1536, 4),
              (256, 256, 128, 2), (256, 384, 256, 0), (1000, 448, 384, 1)],
