@@ -4,11 +4,12 @@
 (src/2d_to_3d_models/run.py:84-102); it is not installed in this image, so this class provides the
 attributes that script touches: .vertices, .faces, .is_empty, .export(path), update_vertices,
 update_faces, remove_unreferenced_vertices, nondegenerate_faces, process.  The GLB carries POSITION
-(float32) + uint32 indices (+ optional per-vertex COLOR_0), which is what the downstream consumer
-loads (src/scene_reconstruction/source/pose_matching_planar.py:882-906).
+(float32) + uint32 indices (+ optional per-vertex COLOR_0, + optional TEXCOORD_0 with a PNG baseColorTexture), which is
+what the downstream consumer loads with load_textures=True (src/scene_reconstruction/source/pose_matching_planar.py:882-906).
 """
 import json
 import struct
+import zlib
 
 import numpy as np
 
@@ -18,8 +19,10 @@ class Mesh:
     torch CUDA tensors, as marching cubes and the GPU cleaners produce them).  The host arrays of a device-born mesh
     are only downloaded when something reads `.vertices` / `.faces`; assigning either drops the device copy."""
 
-    def __init__(self, vertices=None, faces=None, vertex_colors=None, process=True):
+    def __init__(self, vertices=None, faces=None, vertex_colors=None, process=True, uv=None, texture=None):
         self._dv = self._df = None
+        self.uv = None if uv is None else np.asarray(uv, np.float32).reshape(-1, 2)        # glTF convention: v = 0 at the top
+        self.texture = None if texture is None else np.asarray(texture, np.uint8)          # [H, W, 3 | 4]
         self._v = np.zeros((0, 3), np.float64) if vertices is None else np.asarray(vertices, np.float64).reshape(-1, 3)
         self._f = np.zeros((0, 3), np.int64) if faces is None else np.asarray(faces, np.int64).reshape(-1, 3)
         self.vertex_colors = None if vertex_colors is None else np.asarray(vertex_colors, np.uint8)
@@ -32,6 +35,7 @@ class Mesh:
         m._v = m._f = None
         m._dv, m._df = verts, faces
         m.vertex_colors = None
+        m.uv = m.texture = None
         m.metadata = dict(metadata or {})
         return m
 
@@ -94,6 +98,8 @@ class Mesh:
             m = Mesh(self.vertices.copy(), self.faces.copy())
             m.metadata = dict(self.metadata)
         m.vertex_colors = None if self.vertex_colors is None else self.vertex_colors.copy()
+        m.uv = None if getattr(self, "uv", None) is None else self.uv.copy()
+        m.texture = getattr(self, "texture", None)
         return m
 
     def update_vertices(self, mask):
@@ -104,6 +110,8 @@ class Mesh:
         self.vertices = self.vertices[mask]
         if self.vertex_colors is not None:
             self.vertex_colors = self.vertex_colors[mask]
+        if getattr(self, "uv", None) is not None:
+            self.uv = self.uv[mask]
 
     def update_faces(self, mask):
         self.faces = self.faces[np.asarray(mask)]
@@ -141,6 +149,8 @@ class Mesh:
             self.vertices = self.vertices[first[order]]
             if self.vertex_colors is not None:
                 self.vertex_colors = self.vertex_colors[first[order]]
+            if getattr(self, "uv", None) is not None:     # (vertices that differ only in uv are merged: first one wins)
+                self.uv = self.uv[first[order]]
         if validate:
             self.update_faces(self.nondegenerate_faces())
         return self
@@ -156,7 +166,9 @@ class Mesh:
             raw = data.tobytes()
             raw += b"\x00" * (-len(raw) % 4)
             chunks.append(raw)
-            views.append({"buffer": 0, "byteOffset": off, "byteLength": data.nbytes, "target": target})
+            views.append({"buffer": 0, "byteOffset": off, "byteLength": data.nbytes})
+            if target is not None:
+                views[-1]["target"] = target
             return len(views) - 1
 
         accessors.append({"bufferView": add(v, 34962), "componentType": 5126, "count": int(len(v)), "type": "VEC3",
@@ -170,10 +182,27 @@ class Mesh:
             accessors.append({"bufferView": add(c, 34962), "componentType": 5121, "count": int(len(v)), "type": "VEC4",
                               "normalized": True})
             attrs["COLOR_0"] = 2
+        extra = {}
+        prim = {"attributes": attrs, "indices": 1, "mode": 4}
+        uv = getattr(self, "uv", None)
+        tex = getattr(self, "texture", None)
+        if uv is not None and tex is not None and len(uv) == len(v):
+            t = np.ascontiguousarray(uv, np.float32)
+            accessors.append({"bufferView": add(t, 34962), "componentType": 5126, "count": int(len(t)), "type": "VEC2"})
+            attrs["TEXCOORD_0"] = len(accessors) - 1
+            png = np.frombuffer(encode_png(tex), np.uint8)
+            img_view = add(png, None)
+            extra = {"images": [{"bufferView": img_view, "mimeType": "image/png"}],
+                     "samplers": [{"magFilter": 9729, "minFilter": 9729, "wrapS": 33071, "wrapT": 33071}],
+                     "textures": [{"sampler": 0, "source": 0}],
+                     "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicFactor": 0.0,
+                                                             "roughnessFactor": 1.0}}]}
+            prim["material"] = 0
         bin_blob = b"".join(chunks)
         doc = {"asset": {"version": "2.0", "generator": "r3g"}, "scene": 0, "scenes": [{"nodes": [0]}],
-               "nodes": [{"mesh": 0}], "meshes": [{"primitives": [{"attributes": attrs, "indices": 1, "mode": 4}]}],
+               "nodes": [{"mesh": 0}], "meshes": [{"primitives": [prim]}],
                "buffers": [{"byteLength": len(bin_blob)}], "bufferViews": views, "accessors": accessors}
+        doc.update(extra)
         js = json.dumps(doc, separators=(",", ":")).encode()
         js += b" " * (-len(js) % 4)
         total = 12 + 8 + len(js) + 8 + len(bin_blob)
@@ -195,6 +224,20 @@ class Mesh:
             with open(path_s, "wb") as fh:
                 fh.write(data)
         return data
+
+
+def encode_png(img):
+    """uint8 [H, W, 3 | 4] -> PNG bytes (8-bit truecolour, filter 0 on every scanline)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    if img.ndim != 3 or img.shape[2] not in (3, 4):
+        raise ValueError("texture must be [H, W, 3] or [H, W, 4] uint8")
+    h, w, c = img.shape
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * c)], axis=1).tobytes()
+    return b"".join([b"\x89PNG\r\n\x1a\n", chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)),
+                     chunk(b"IDAT", zlib.compress(raw, 6)), chunk(b"IEND", b"")])
 
 
 def load_glb(data):

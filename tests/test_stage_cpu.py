@@ -69,6 +69,9 @@ def test_filesystem_contract(tmp_path, capsys):
     for stem in made:
         data = (out / stem / (stem + ".glb")).read_bytes()
         assert data[:4] == b"glTF"
+        from gltf_validate import validate_glb                     # independent glTF 2.0 checks (tests/gltf_validate.py)
+        got = validate_glb(data)
+        assert len(got["positions"]) > 0 and len(got["indices"]) > 0
     rep = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
     assert rep["objects"] == 2 and rep["ok"] == 2
 

@@ -40,6 +40,9 @@ def test_stage_script_writes_glbs(tmp_path):
     for stem in os.listdir(out):
         m = load_glb(str(out / stem / (stem + ".glb")))
         assert len(m.faces) > 0 and len(m.faces) <= 40000          # FaceReducer bound
+        from gltf_validate import validate_glb                     # independent glTF 2.0 checks (tests/gltf_validate.py)
+        got = validate_glb((out / stem / (stem + ".glb")).read_bytes())
+        assert np.array_equal(got["indices"].astype(np.int64), m.faces) and len(got["positions"]) == len(m.vertices)
         assert np.isfinite(m.vertices).all() and np.abs(m.vertices).max() <= 1.02
 
 
