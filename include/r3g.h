@@ -195,11 +195,15 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
  * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
- * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 tile | 10 = 256x128 | 16 | 32 = deep ring), "gemm_raster"
- * (-1 auto | tile columns per rasterisation group), "gemm_phased" (1: 256x256 tiles on the phased counted-vmcnt kernel),
- * "attn_generation" (2 | 1 = the first-round kernel), "attn_pipelined" (0), "attn_ablate" (timing-only masks), "mc_rows" (4 | 8 | 16 | 32 node rows per
- * wave in the marching-cubes row kernel).  None of them changes a result bit, except fuse_qkv / batch_mods / cfg_dedup
- * (different summation order, same function). */
+ * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 two-stage | 10 = 256x128 | 11 = 256x256 phased | 12 = phased,
+ * persistent grid | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"
+ * (1: 256x256 tiles on the phased counted-vmcnt kernel), "gemm_persistent" (1: its persistent form for bf16 outputs
+ * with more tiles than CUs), "gemm_num_cu" (CUs the tile rules assume, default 256), "attn_generation" (2 default |
+ * 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_pipelined" (0), "attn_ablate"
+ * (timing-only masks, results are garbage), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
+ * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel).  None of them changes a
+ * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation
+ * (different rounding points inside the softmax). */
 int r3g_set_option(const char* name, int value);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);
