@@ -29,7 +29,7 @@ MANIFEST = os.path.join(OBJ, "manifest.json")
 STAMP = os.path.join(HERE, "libr3g.digest")     # travels with the .so (the GPU box gets both)
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-missing-braces", "-I" + INC, "-I" + CSRC]
-PER_FILE = {"mc_kernels.hip": ["-ffp-contract=off"]}
+PER_FILE = {"mc_kernels.hip": ["-ffp-contract=off"], "tex_kernels.hip": ["-ffp-contract=off"]}
 
 
 def sources():

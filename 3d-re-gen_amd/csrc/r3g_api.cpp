@@ -9,6 +9,7 @@
 #include "../../include/r3g.h"
 #include "r3g_ctx.h"
 #include "mesh_kernels.h"
+#include "tex_kernels.h"
 
 namespace r3g {
 static thread_local char g_err[512] = "";
@@ -84,6 +85,7 @@ void r3g_destroy(r3g_ctx* ctx) {
     (void)hipSetDevice(c->device);
     if (c->mc_ws) (void)hipFree(c->mc_ws);
     if (c->mesh_ws) (void)hipFree(c->mesh_ws);
+    if (c->tex_ws) (void)hipFree(c->tex_ws);
     if (c->h_small) (void)hipHostFree(c->h_small);
     c->release_model();
     delete c;
@@ -197,6 +199,73 @@ int r3g_mesh_cluster_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32
     hipError_t e = mesh_cluster_faces(c->mesh_ws, c->mesh_ws_bytes, (unsigned*)c->h_small, d_verts, n_verts, d_faces,
                                       n_faces, max_faces, (hipStream_t)stream);
     return e == hipSuccess ? R3G_OK : hip_fail(e, "mesh_cluster_faces");
+}
+
+// ---- texture stage ------------------------------------------------------------------------------------------------
+int r3g_tex_rasterize(r3g_ctx* ctx, const float* d_pos_clip, int64_t n_verts, const int32_t* d_tri, int64_t n_faces, int height,
+                      int width, int32_t* d_findices, float* d_bary, void* stream) {
+    if (!ctx || !d_findices || !d_bary) return fail(R3G_ERR_INVALID, "r3g_tex_rasterize: null argument");
+    if (height < 1 || width < 1 || height > 16384 || width > 16384)
+        return fail(R3G_ERR_INVALID, "r3g_tex_rasterize: image size out of range");
+    if (n_verts < 0 || n_faces < 0 || n_faces >= (1ll << 30) || (n_faces && (!d_pos_clip || !d_tri)))
+        return fail(R3G_ERR_INVALID, "r3g_tex_rasterize: bad mesh arguments");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    int rc = c->reserve(&c->tex_ws, &c->tex_ws_bytes, 8 * (size_t)height * width, "hipMalloc(z-buffer)");
+    if (rc) return rc;
+    hipError_t e = tex_rasterize(d_pos_clip, d_tri, (int)n_faces, height, width, (unsigned long long*)c->tex_ws, d_findices,
+                                 d_bary, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_rasterize");
+}
+
+int r3g_tex_interpolate(r3g_ctx* ctx, const float* d_attr, int channels, const int32_t* d_tri, const int32_t* d_findices,
+                        const float* d_bary, int64_t n_pixels, float* d_out, void* stream) {
+    if (!ctx || !d_attr || !d_tri || !d_findices || !d_bary || !d_out) return fail(R3G_ERR_INVALID, "r3g_tex_interpolate: null argument");
+    if (channels < 1 || channels > 64 || n_pixels < 0) return fail(R3G_ERR_INVALID, "r3g_tex_interpolate: bad sizes");
+    hipError_t e = tex_interpolate(d_attr, channels, d_tri, d_findices, d_bary, n_pixels, d_out, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_interpolate");
+}
+
+int r3g_tex_view_weight(r3g_ctx* ctx, const int32_t* d_findices, const float* d_depth, const float* d_normal, int height,
+                        int width, float cos_threshold, float depth_edge, float view_weight, float power, float* d_weight,
+                        void* stream) {
+    if (!ctx || !d_findices || !d_depth || !d_normal || !d_weight) return fail(R3G_ERR_INVALID, "r3g_tex_view_weight: null argument");
+    if (height < 1 || width < 1) return fail(R3G_ERR_INVALID, "r3g_tex_view_weight: bad sizes");
+    hipError_t e = tex_view_weight(d_findices, d_depth, d_normal, height, width, cos_threshold, depth_edge, view_weight, power,
+                                   d_weight, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_view_weight");
+}
+
+int r3g_tex_bake(r3g_ctx* ctx, const float* d_image, const float* d_weight, const int32_t* d_findices, const float* d_bary,
+                 const float* d_uv, const int32_t* d_uv_tri, int64_t n_pixels, int tex_size, uint64_t* d_acc, void* stream) {
+    if (!ctx || !d_image || !d_weight || !d_findices || !d_bary || !d_uv || !d_uv_tri || !d_acc)
+        return fail(R3G_ERR_INVALID, "r3g_tex_bake: null argument");
+    if (tex_size < 1 || tex_size > 16384 || n_pixels < 0) return fail(R3G_ERR_INVALID, "r3g_tex_bake: bad sizes");
+    hipError_t e = tex_bake(d_image, d_weight, d_findices, d_bary, d_uv, d_uv_tri, n_pixels, tex_size, (unsigned long long*)d_acc,
+                            (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_bake");
+}
+
+int r3g_tex_bake_finalize(r3g_ctx* ctx, const uint64_t* d_acc, int tex_size, float* d_texture, uint8_t* d_mask, void* stream) {
+    if (!ctx || !d_acc || !d_texture || !d_mask) return fail(R3G_ERR_INVALID, "r3g_tex_bake_finalize: null argument");
+    if (tex_size < 1 || tex_size > 16384) return fail(R3G_ERR_INVALID, "r3g_tex_bake_finalize: bad sizes");
+    hipError_t e = tex_bake_finalize((const unsigned long long*)d_acc, tex_size, d_texture, d_mask, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_bake_finalize");
+}
+
+int r3g_tex_inpaint(r3g_ctx* ctx, float* d_texture, uint8_t* d_mask, int tex_size, const int32_t* d_findices_uv,
+                    const float* d_bary_uv, const float* d_verts, int64_t n_verts, const int32_t* d_pos_tri, const float* d_uv,
+                    const int32_t* d_uv_tri, int64_t n_faces, int dilate_iters, int* rounds_out, void* stream) {
+    if (!ctx || !d_texture || !d_mask || !d_findices_uv || !d_bary_uv || !d_verts || !d_pos_tri || !d_uv || !d_uv_tri)
+        return fail(R3G_ERR_INVALID, "r3g_tex_inpaint: null argument");
+    if (tex_size < 1 || tex_size > 16384 || n_verts < 1 || n_faces < 1 || n_verts >= (1ll << 31) || n_faces >= (1ll << 30) ||
+        dilate_iters < 0 || dilate_iters > 4096)
+        return fail(R3G_ERR_INVALID, "r3g_tex_inpaint: bad sizes");
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    int rc = c->reserve(&c->tex_ws, &c->tex_ws_bytes, tex_inpaint_workspace(n_verts, tex_size), "hipMalloc(inpaint workspace)");
+    if (rc) return rc;
+    hipError_t e = tex_inpaint(c->tex_ws, (unsigned*)c->h_small, d_texture, d_mask, tex_size, d_findices_uv, d_bary_uv, d_verts,
+                               n_verts, d_pos_tri, d_uv, d_uv_tri, n_faces, dilate_iters, rounds_out, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_inpaint");
 }
 
 }  // extern "C"

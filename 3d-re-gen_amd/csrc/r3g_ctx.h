@@ -28,6 +28,9 @@ struct Ctx {
     // mesh cleaners
     char* mesh_ws = nullptr;
     size_t mesh_ws_bytes = 0;
+    // texture stage (z-buffer / inpainting workspace)
+    char* tex_ws = nullptr;
+    size_t tex_ws_bytes = 0;
 
     int reserve(char** buf, size_t* have, size_t need, const char* what);
     void* model = nullptr;  // r3g::Model (model.cpp)

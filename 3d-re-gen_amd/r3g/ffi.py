@@ -40,6 +40,12 @@ SYMBOLS = {
     "r3g_mesh_remove_degenerate": (_I, [_P, _P, _I64P, _P, _I64P, _P]),
     "r3g_mesh_reduce_faces": (_I, [_P, _P, _I64P, _P, _I64P, ctypes.c_int64, _P]),
     "r3g_mesh_cluster_faces": (_I, [_P, _P, _I64P, _P, _I64P, ctypes.c_int64, _P]),
+    "r3g_tex_rasterize": (_I, [_P, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _I, _P, _P, _P]),
+    "r3g_tex_interpolate": (_I, [_P, _P, _I, _P, _P, _P, ctypes.c_int64, _P, _P]),
+    "r3g_tex_view_weight": (_I, [_P, _P, _P, _P, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P]),
+    "r3g_tex_bake": (_I, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _I, _P, _P]),
+    "r3g_tex_bake_finalize": (_I, [_P, _P, _I, _P, _P, _P]),
+    "r3g_tex_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _I, ctypes.POINTER(_I), _P]),
     "r3g_model_create": (_I, [_P, _P]),
     "r3g_model_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
     "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),

@@ -103,6 +103,39 @@ int r3g_mesh_reduce_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_
 int r3g_mesh_cluster_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32_t* d_faces, int64_t* n_faces,
                            int64_t max_faces, void* stream);
 
+/* ---- texture stage: native pieces ------------------------------------------------------------
+ * SURVEY.md 8(f) rank 3.  Upstream's Hunyuan3DPaintPipeline (reference call site src/2d_to_3d_models/run.py:97, built at
+ * :126-128) uses two native extensions, `custom_rasterizer` (CUDA) and `mesh_processor.cpp`, and bakes the generated views
+ * into a UV texture in its MeshRender.  These are their gfx950 counterparts; the two diffusion UNets are NOT part of this
+ * library.  All buffers are device pointers; images are row-major [H][W][C] float32, row 0 = top.
+ *   rasterize     ~ custom_rasterizer.rasterize(pos, tri, (H, W)): pos_clip float32 [V][4], tri int32 [F][3] ->
+ *                   findices int32 [H][W] (face + 1, 0 = empty), bary float32 [H][W][3] (perspective-correct).  Pixel
+ *                   (ix, iy) samples (ix + 0.5, iy + 0.5) of the screen x = (x/w/2 + 1/2)(W-1) + 1/2; nearest depth wins, equal
+ *                   depths go to the smaller face index (result independent of scheduling).
+ *   interpolate   ~ custom_rasterizer.interpolate(attr, findices, bary, tri): out[p] = sum_k bary[p][k] attr[tri[f][k]].
+ *   view_weight   baking weight of a view: view_weight * cos^power of the view-space normal, 0 below cos_threshold, on
+ *                   the silhouette and where the depth jumps by more than depth_edge between 4-neighbours.
+ *   bake          scatters a view (image float32 [H][W][3] in [0,1]) into acc uint64 [T][T][4] (zero it first; fixed point,
+ *                   integer atomics: exact, order independent); texel = round(uv * (T-1)), v = 0 is the top row.
+ *   bake_finalize acc -> texture float32 [T][T][3], mask uint8 [T][T] (1 = painted).
+ *   inpaint       ~ mesh_processor.meshVerticeInpaint + the dilation upstream does with cv2: vertex colours from painted
+ *                   texels, propagation along mesh edges (weights 1/(d^2 + 1e-6), Jacobi rounds until nothing changes),
+ *                   unpainted covered texels from the vertex colours (mask 2), `dilate_iters` steps into empty texels (mask
+ *                   3).  findices_uv / bary_uv = rasterize() of the mesh in UV space.  Synchronises the stream. */
+int r3g_tex_rasterize(r3g_ctx* ctx, const float* d_pos_clip, int64_t n_verts, const int32_t* d_tri, int64_t n_faces, int height,
+                      int width, int32_t* d_findices, float* d_bary, void* stream);
+int r3g_tex_interpolate(r3g_ctx* ctx, const float* d_attr, int channels, const int32_t* d_tri, const int32_t* d_findices,
+                        const float* d_bary, int64_t n_pixels, float* d_out, void* stream);
+int r3g_tex_view_weight(r3g_ctx* ctx, const int32_t* d_findices, const float* d_depth, const float* d_normal, int height,
+                        int width, float cos_threshold, float depth_edge, float view_weight, float power, float* d_weight,
+                        void* stream);
+int r3g_tex_bake(r3g_ctx* ctx, const float* d_image, const float* d_weight, const int32_t* d_findices, const float* d_bary,
+                 const float* d_uv, const int32_t* d_uv_tri, int64_t n_pixels, int tex_size, uint64_t* d_acc, void* stream);
+int r3g_tex_bake_finalize(r3g_ctx* ctx, const uint64_t* d_acc, int tex_size, float* d_texture, uint8_t* d_mask, void* stream);
+int r3g_tex_inpaint(r3g_ctx* ctx, float* d_texture, uint8_t* d_mask, int tex_size, const int32_t* d_findices_uv,
+                    const float* d_bary_uv, const float* d_verts, int64_t n_verts, const int32_t* d_pos_tri, const float* d_uv,
+                    const int32_t* d_uv_tri, int64_t n_faces, int dilate_iters, int* rounds_out, void* stream);
+
 /* ---- shape model (DiT + ShapeVAE + DINOv2 conditioner) -----------------------------------------
  * Replaces the modules `Hunyuan3DDiTFlowMatchingPipeline.from_pretrained` instantiates from the
  * checkpoint's config.yaml (reference call sites src/2d_to_3d_models/run.py:122-124,204-206;
