@@ -245,6 +245,18 @@ int r3g_tex_bake(r3g_ctx* ctx, const float* d_image, const float* d_weight, cons
     return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_bake");
 }
 
+int r3g_tex_bake_gather(r3g_ctx* ctx, const int32_t* d_findices_uv, const float* d_bary_uv, const float* d_clip_uv,
+                        const int32_t* d_uv_tri, int tex_size, const float* d_image, const float* d_weight,
+                        const int32_t* d_findices, const float* d_depth, int height, int width, float depth_eps, uint64_t* d_acc,
+                        void* stream) {
+    if (!ctx || !d_findices_uv || !d_bary_uv || !d_clip_uv || !d_uv_tri || !d_image || !d_weight || !d_findices || !d_depth || !d_acc)
+        return fail(R3G_ERR_INVALID, "r3g_tex_bake_gather: null argument");
+    if (tex_size < 1 || tex_size > 16384 || height < 1 || width < 1) return fail(R3G_ERR_INVALID, "r3g_tex_bake_gather: bad sizes");
+    hipError_t e = tex_bake_gather(d_findices_uv, d_bary_uv, d_clip_uv, d_uv_tri, tex_size, d_image, d_weight, d_findices, d_depth,
+                                   height, width, depth_eps, (unsigned long long*)d_acc, (hipStream_t)stream);
+    return e == hipSuccess ? R3G_OK : hip_fail(e, "tex_bake_gather");
+}
+
 int r3g_tex_bake_finalize(r3g_ctx* ctx, const uint64_t* d_acc, int tex_size, float* d_texture, uint8_t* d_mask, void* stream) {
     if (!ctx || !d_acc || !d_texture || !d_mask) return fail(R3G_ERR_INVALID, "r3g_tex_bake_finalize: null argument");
     if (tex_size < 1 || tex_size > 16384) return fail(R3G_ERR_INVALID, "r3g_tex_bake_finalize: bad sizes");

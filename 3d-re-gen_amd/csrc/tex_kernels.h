@@ -17,6 +17,9 @@ hipError_t tex_view_weight(const int32_t* findices, const float* depth, const fl
                            hipStream_t s);
 hipError_t tex_bake(const float* image, const float* weight, const int32_t* findices, const float* bary, const float* uv,
                     const int32_t* uv_tri, int64_t npix, int T, unsigned long long* acc, hipStream_t s);
+hipError_t tex_bake_gather(const int32_t* findices_uv, const float* bary_uv, const float* clip_uv, const int32_t* uv_tri, int T,
+                           const float* image, const float* weight, const int32_t* findices, const float* depth, int H, int W,
+                           float depth_eps, unsigned long long* acc, hipStream_t s);
 hipError_t tex_bake_finalize(const unsigned long long* acc, int T, float* tex, uint8_t* mask, hipStream_t s);
 
 // bytes of workspace tex_inpaint needs for V vertices and a T x T texture

@@ -11,6 +11,8 @@
 //                      image does not depend on scheduling.  One wave per face, lanes over its bounding box.
 //   tex_interpolate    per-pixel attribute = sum of barycentric * per-corner attribute (any index array: positions, uv).
 //   tex_view_weight    per-pixel baking weight: view_weight * cos^power, zero below a cosine threshold and on depth edges.
+//   tex_bake_gather    texel-centric baking (the pipeline's default): each covered texel projects itself into the view,
+//                      tests visibility against the view's depth buffer and samples the image bilinearly; no atomics.
 //   tex_bake           scatter a view's colours into texel accumulators (64-bit fixed point, integer atomics: exact and
 //                      order independent) ; tex_bake_finalize divides.
 //   tex_inpaint        vertex colours from painted texels (smallest corner id wins) -> propagation over mesh edges with
@@ -187,6 +189,54 @@ __global__ __launch_bounds__(256) void bake_kernel(const float* __restrict__ ima
     atomicAdd(&acc[4 * tex + 3], (unsigned long long)wq);
 }
 
+// Texel-centric baking: every covered texel finds its own place in the view (its clip position comes from the UV-space
+// rasterisation of the mesh), checks that it is the surface the view sees there (z-buffer depth of the nearest pixel),
+// takes that pixel's baking weight and a bilinear sample of the image.  One thread per texel: no atomics, and the texture
+// is as dense as the UV raster, however coarse the view is.
+__global__ __launch_bounds__(256) void bake_gather_kernel(const int32_t* __restrict__ findices_uv, const float* __restrict__ bary_uv,
+                                                          const float* __restrict__ clip_uv, const int32_t* __restrict__ uv_tri,
+                                                          int64_t ntexel, const float* __restrict__ image,
+                                                          const float* __restrict__ weight, const int32_t* __restrict__ findices,
+                                                          const float* __restrict__ depth, int H, int W, float depth_eps,
+                                                          unsigned long long* __restrict__ acc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntexel) return;
+    const int id = findices_uv[i];
+    if (id <= 0) return;
+    const int32_t* t = uv_tri + 3 * (int64_t)(id - 1);
+    const float b0 = bary_uv[3 * i], b1 = bary_uv[3 * i + 1], b2 = bary_uv[3 * i + 2];
+    float p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        p[k] = b0 * clip_uv[4 * (int64_t)t[0] + k] + b1 * clip_uv[4 * (int64_t)t[1] + k] + b2 * clip_uv[4 * (int64_t)t[2] + k];
+    if (!(p[3] > 0.f)) return;
+    const float sx = (p[0] / p[3] * 0.5f + 0.5f) * (float)(W - 1) + 0.5f;
+    const float sy = (p[1] / p[3] * 0.5f + 0.5f) * (float)(H - 1) + 0.5f;
+    const float z = p[2] / p[3];
+    const int px = (int)floorf(sx), py = (int)floorf(sy);
+    if (px < 0 || py < 0 || px >= W || py >= H) return;
+    const int64_t pix = (int64_t)py * W + px;
+    const float w = weight[pix];
+    if (findices[pix] <= 0 || !(w > 0.f) || z > depth[pix] + depth_eps) return;
+    const unsigned wq = (unsigned)(fminf(w, 65535.f) * 65536.f + 0.5f);
+    if (wq == 0u) return;
+    // bilinear sample at the pixel-centre coordinates (sx - 0.5, sy - 0.5), clamped at the border
+    const float fx = sx - 0.5f, fy = sy - 0.5f;
+    int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    const float ax = fx - (float)x0, ay = fy - (float)y0;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float c00 = image[3 * ((int64_t)y0 * W + x0) + c], c01 = image[3 * ((int64_t)y0 * W + x1) + c];
+        const float c10 = image[3 * ((int64_t)y1 * W + x0) + c], c11 = image[3 * ((int64_t)y1 * W + x1) + c];
+        const float top = c00 + (c01 - c00) * ax, bot = c10 + (c11 - c10) * ax;
+        acc[4 * i + c] += (unsigned long long)wq * q16(top + (bot - top) * ay);
+    }
+    acc[4 * i + 3] += (unsigned long long)wq;
+}
+
 __global__ __launch_bounds__(256) void bake_finalize_kernel(const unsigned long long* __restrict__ acc, int64_t n, float* __restrict__ tex,
                                                             uint8_t* __restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -346,6 +396,15 @@ hipError_t tex_view_weight(const int32_t* findices, const float* depth, const fl
 hipError_t tex_bake(const float* image, const float* weight, const int32_t* findices, const float* bary, const float* uv,
                     const int32_t* uv_tri, int64_t npix, int T, unsigned long long* acc, hipStream_t s) {
     hipLaunchKernelGGL(bake_kernel, blocks(npix), dim3(256), 0, s, image, weight, findices, bary, uv, uv_tri, npix, T, acc);
+    return hipGetLastError();
+}
+
+hipError_t tex_bake_gather(const int32_t* findices_uv, const float* bary_uv, const float* clip_uv, const int32_t* uv_tri, int T,
+                           const float* image, const float* weight, const int32_t* findices, const float* depth, int H, int W,
+                           float depth_eps, unsigned long long* acc, hipStream_t s) {
+    const int64_t n = (int64_t)T * T;
+    hipLaunchKernelGGL(bake_gather_kernel, blocks(n), dim3(256), 0, s, findices_uv, bary_uv, clip_uv, uv_tri, n, image, weight,
+                       findices, depth, H, W, depth_eps, acc);
     return hipGetLastError();
 }
 

@@ -1,0 +1,164 @@
+"""hy3dgen.texgen.pipelines -- MI355X mirror of upstream's texture pipeline entry point.
+
+Reference call sites: src/2d_to_3d_models/run.py:17 (import), :126-128 / :207-209 (`from_pretrained`), :97
+(`mesh = pipeline_texgen(mesh, image=image)`).  Upstream's __call__ (recalled): delight the input image with an
+image-to-image diffusion model -> UV-unwrap the mesh (xatlas) -> render normal / position maps of six fixed views with the
+native `custom_rasterizer` -> generate the six views with a multiview diffusion UNet -> back-project and blend them into a
+UV texture -> inpaint what no view saw (`mesh_processor.meshVerticeInpaint` + cv2) -> textured mesh.
+
+What exists here (partial): everything EXCEPT the two diffusion models.  The native pieces run as HIP
+kernels behind the C ABI (r3g.texops: rasterise, interpolate, view weights, fixed-point baking, vertex-propagation
+inpainting); the unwrap is a per-face chart atlas (r3g.uvatlas).  The views that get baked are
+  * the views a caller-supplied `multiview_model(image, views) -> list of RGB images` produces, when one is given, or
+  * by default ONLY the input image, registered to the front view of the mesh (its alpha silhouette against the mesh
+    silhouette); every texel no view saw is filled by colour propagation over the mesh.
+`self.source` says which, and the stage report repeats it: a GLB textured from one view is NOT what upstream produces."""
+import os
+
+import numpy as np
+
+# (elevation, azimuth, blend weight) of upstream's six candidate views
+DEFAULT_VIEWS = [(0, 0, 1.0), (0, 90, 0.1), (0, 180, 0.5), (0, 270, 0.1), (90, 0, 0.05), (-90, 0, 0.05)]
+
+
+def view_rotation(elev_deg, azim_deg):
+    """world -> camera rotation: azimuth about +y, then elevation about +x; the camera looks down -z, +y is up"""
+    a, e = np.deg2rad(azim_deg), np.deg2rad(elev_deg)
+    ry = np.array([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]])
+    rx = np.array([[1, 0, 0], [0, np.cos(e), -np.sin(e)], [0, np.sin(e), np.cos(e)]])
+    return (rx @ ry).astype(np.float32)
+
+
+def ortho_clip(cam_xyz, centre, half_extent, depth_half):
+    """orthographic clip coordinates: x right, image row 0 at the top (+y up), nearer = smaller depth"""
+    out = np.ones((len(cam_xyz), 4), np.float32)
+    out[:, 0] = (cam_xyz[:, 0] - centre[0]) / half_extent[0]
+    out[:, 1] = -(cam_xyz[:, 1] - centre[1]) / half_extent[1]
+    out[:, 2] = -cam_xyz[:, 2] / depth_half
+    return out
+
+
+class Hunyuan3DPaintPipeline:
+    implemented = True
+
+    def __init__(self, texture_size=None, render_size=None, multiview_model=None, views=None, cos_threshold=0.1,
+                 depth_edge=0.02, power=4.0, dilate_iters=8, device=None):
+        # upstream: texture_size 2048, render_size 2048; R3G_TEX_SIZE / R3G_TEX_RENDER override the defaults (tests)
+        self.texture_size = int(texture_size or os.environ.get("R3G_TEX_SIZE", 2048))
+        self.render_size = int(render_size or os.environ.get("R3G_TEX_RENDER", 1024))
+        self.multiview_model = multiview_model
+        self.views = list(views) if views is not None else list(DEFAULT_VIEWS)
+        self.cos_threshold, self.depth_edge, self.power = float(cos_threshold), float(depth_edge), float(power)
+        self.dilate_iters = int(dilate_iters)
+        self.device = device
+        self.last_stats = {}
+
+    @property
+    def source(self):
+        if self.multiview_model is not None:
+            return "multiview model supplied by the caller, %d views baked" % len(self.views)
+        return "input view only (no multiview diffusion model on this path); unseen texels filled by propagation over the mesh"
+
+    @classmethod
+    def from_pretrained(cls, model_path=None, subfolder=None, **kwargs):
+        """upstream loads the delight and multiview diffusion checkpoints here; this path has neither (see module doc)"""
+        allowed = ("texture_size", "render_size", "multiview_model", "views", "cos_threshold", "depth_edge", "power",
+                   "dilate_iters", "device")
+        return cls(**{k: v for k, v in kwargs.items() if k in allowed})
+
+    # -- helpers -----------------------------------------------------------------------------------------------------
+    def _device(self):
+        import torch
+        return torch.device(self.device or ("cuda:%d" % torch.cuda.current_device()))
+
+    def _front_image(self, image):
+        """RGBA PIL image -> (rgb float32 [R, R, 3] in [0, 1], alpha float32 [R, R], alpha bbox in [0, 1] image coordinates)"""
+        from PIL import Image
+        r = self.render_size
+        img = image.convert("RGBA") if image.mode != "RGBA" else image
+        arr = np.asarray(img.resize((r, r), Image.BILINEAR), np.float32) / 255.0
+        alpha = arr[..., 3]
+        ys, xs = np.nonzero(alpha > 0.5)
+        if len(xs) == 0:
+            box = (0.0, 0.0, 1.0, 1.0)
+        else:
+            box = (xs.min() / r, ys.min() / r, (xs.max() + 1) / r, (ys.max() + 1) / r)
+        return np.ascontiguousarray(arr[..., :3]), np.ascontiguousarray(alpha), box
+
+    def __call__(self, mesh, image=None, **kwargs):
+        import torch
+        from r3g import texops, uvatlas
+        from r3g.mesh import Mesh
+        if image is None:
+            raise ValueError("Hunyuan3DPaintPipeline needs the object's image")
+        if mesh.is_empty:
+            return mesh
+        dev = self._device()
+        v = np.ascontiguousarray(mesh.vertices, np.float32)
+        f = np.ascontiguousarray(mesh.faces, np.int32)
+        nf = len(f)
+        T, R = self.texture_size, self.render_size
+        uv, uv_tri = uvatlas.face_atlas(nf, T)
+        e1, e2 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+        fn = np.cross(e1, e2)
+        fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+        corner_n = np.repeat(fn.astype(np.float32), 3, axis=0)                    # flat normals, one per face corner
+
+        d_f, d_uv, d_uvt = torch.from_numpy(f).to(dev), torch.from_numpy(uv).to(dev), torch.from_numpy(uv_tri).to(dev)
+        rgb, alpha, abox = self._front_image(image)
+        if self.multiview_model is not None:
+            images = [np.ascontiguousarray(np.asarray(im, np.float32)) for im in self.multiview_model(image, self.views)]
+            views = self.views
+        else:
+            images, views = [rgb], [(0, 0, 1.0)]
+        radius = float(np.abs(v).max()) * 1.05 + 1e-6
+
+        # the mesh in UV space: which face and where inside it every texel is
+        fi_uv, bary_uv = texops.rasterize(torch.from_numpy(uvatlas.uv_clip(uv)).to(dev), d_uvt, T, T)
+
+        def bake_views(sign):
+            acc = texops.new_accumulator(T, dev)
+            for (elev, azim, vw), img in zip(views, images):
+                rot = view_rotation(elev, azim)
+                cam = v @ rot.T
+                if self.multiview_model is None:
+                    # register the mesh silhouette's bounding box with the alpha bounding box of the input image
+                    lo, hi = cam[:, :2].min(axis=0), cam[:, :2].max(axis=0)
+                    size = np.maximum(hi - lo, 1e-6)
+                    wx, wy = max(abox[2] - abox[0], 1e-3), max(abox[3] - abox[1], 1e-3)
+                    half = np.array([size[0] / wx, size[1] / wy], np.float32) * 0.5
+                    cx = lo[0] + size[0] * 0.5 - ((abox[0] + abox[2]) * 0.5 - 0.5) * 2.0 * half[0]
+                    cy = lo[1] + size[1] * 0.5 + ((abox[1] + abox[3]) * 0.5 - 0.5) * 2.0 * half[1]
+                    centre = (cx, cy)
+                else:
+                    half, centre = np.array([radius, radius], np.float32), (0.0, 0.0)
+                clip = ortho_clip(cam, centre, half, radius * 2.0)
+                d_clip = torch.from_numpy(clip).to(dev)
+                fi, bary = texops.rasterize(d_clip, d_f, R, R)
+                depth = texops.interpolate(d_clip[:, 2:3].contiguous(), d_f, fi, bary)[..., 0]
+                nmap = texops.interpolate(torch.from_numpy(np.ascontiguousarray(sign * (corner_n @ rot.T), np.float32)).to(dev),
+                                          d_uvt, fi, bary)
+                w = texops.view_weight(fi, depth, nmap, self.cos_threshold, self.depth_edge, vw, self.power)
+                if self.multiview_model is None:
+                    w = w * torch.from_numpy((alpha > 0.5).astype(np.float32)).to(dev)   # only what the image actually shows
+                if img.shape[0] != R or img.shape[1] != R:
+                    raise ValueError("view images must be %d x %d" % (R, R))
+                # texel-centric: every covered texel looks itself up in this view (UV vertex = face corner)
+                texops.bake_gather(fi_uv, bary_uv, torch.from_numpy(np.ascontiguousarray(clip[f].reshape(-1, 4))).to(dev), d_uvt,
+                                   torch.from_numpy(img).to(dev), w, fi, depth, acc, self.depth_edge)
+            return texops.bake_finalize(acc)
+
+        tex, mask = bake_views(1.0)
+        if int((mask > 0).sum()) == 0:
+            tex, mask = bake_views(-1.0)       # a mesh wound the other way round: its normals point inwards
+        painted = int((mask > 0).sum())
+        tex, mask, rounds = texops.inpaint(tex, mask, fi_uv, bary_uv, torch.from_numpy(v).to(dev), d_f, d_uv, d_uvt,
+                                           self.dilate_iters)
+        covered = int((fi_uv > 0).sum())
+        self.last_stats = {"texels_covered": covered, "texels_painted_by_views": painted,
+                           "texels_coloured": int((mask > 0).sum()), "propagation_rounds": rounds, "source": self.source}
+        tex8 = (tex.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).cpu().numpy()
+        out = Mesh(v[f].reshape(-1, 3), uv_tri, uv=uv, texture=tex8)
+        out.metadata = dict(getattr(mesh, "metadata", {}))
+        out.metadata["texture_source"] = self.source
+        return out

@@ -84,36 +84,59 @@ class WorkQueue:
 
 
 def gather_meshes(local, dst=0):
-    """local: list of (index, vertices float32 [nV,3], faces int [nF,3]) tensors / arrays produced on this rank.
-    Returns on rank `dst` a dict index -> (vertices float32 ndarray, faces int32 ndarray) of ALL ranks; {} elsewhere."""
+    """local: list of (index, vertices float32 [nV,3], faces int [nF,3]) or (index, vertices, faces, uv float32 [nV,2],
+    texture uint8 [T,T,C]) tensors / arrays produced on this rank.
+    Returns on rank `dst` a dict index -> (vertices float32 ndarray, faces int32 ndarray[, uv, texture]) of ALL ranks; {}
+    elsewhere."""
     dev = _comm_device()
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = []
-    for idx, v, f in local:
+    for item in local:
+        idx, v, f = item[:3]
         v = torch.as_tensor(v).to(device=dev, dtype=torch.float32).contiguous().view(-1, 3)
         f = torch.as_tensor(f).to(device=dev, dtype=torch.int32).contiguous().view(-1, 3)
-        mine.append((int(idx), v, f))
+        uv = tex = None
+        if len(item) > 3 and item[3] is not None and item[4] is not None:
+            uv = torch.as_tensor(item[3]).to(device=dev, dtype=torch.float32).contiguous().view(-1, 2)
+            tex = torch.as_tensor(item[4]).to(device=dev, dtype=torch.uint8).contiguous()
+        mine.append((int(idx), v, f, uv, tex))
     meta = [None] * world
-    dist.all_gather_object(meta, [(i, int(v.shape[0]), int(f.shape[0])) for i, v, f in mine])
+    dist.all_gather_object(meta, [(i, int(v.shape[0]), int(f.shape[0]), None if tex is None else tuple(tex.shape))
+                                  for i, v, f, uv, tex in mine])
+
+    def pack(v, f, uv, tex):
+        return (v.cpu().numpy(), f.cpu().numpy()) if tex is None else (v.cpu().numpy(), f.cpu().numpy(), uv.cpu().numpy(),
+                                                                      tex.cpu().numpy())
     out = {}
     if rank == dst:
-        for i, v, f in mine:
-            out[i] = (v.cpu().numpy(), f.cpu().numpy())
+        for i, v, f, uv, tex in mine:
+            out[i] = pack(v, f, uv, tex)
         for r in range(world):
             if r == dst:
                 continue
-            for (i, nv, nf) in meta[r]:       # the sender walks the same list in the same order
+            for (i, nv, nf, tshape) in meta[r]:       # the sender walks the same list in the same order
                 v = torch.empty((nv, 3), dtype=torch.float32, device=dev)
                 f = torch.empty((nf, 3), dtype=torch.int32, device=dev)
                 if nv:
                     dist.recv(v, src=r)
                 if nf:
                     dist.recv(f, src=r)
-                out[i] = (v.cpu().numpy(), f.cpu().numpy())
+                uv = tex = None
+                if tshape is not None:
+                    uv = torch.empty((nv, 2), dtype=torch.float32, device=dev)
+                    tex = torch.empty(tshape, dtype=torch.uint8, device=dev)
+                    if nv:
+                        dist.recv(uv, src=r)
+                    dist.recv(tex, src=r)
+                out[i] = pack(v, f, uv, tex)
     else:
-        for i, v, f in mine:
+        for i, v, f, uv, tex in mine:
             if v.shape[0]:
                 dist.send(v, dst=dst)
             if f.shape[0]:
                 dist.send(f, dst=dst)
+            if tex is not None:
+                if v.shape[0]:
+                    dist.send(uv, dst=dst)
+                dist.send(tex, dst=dst)
     return out

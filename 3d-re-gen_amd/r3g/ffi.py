@@ -44,6 +44,7 @@ SYMBOLS = {
     "r3g_tex_interpolate": (_I, [_P, _P, _I, _P, _P, _P, ctypes.c_int64, _P, _P]),
     "r3g_tex_view_weight": (_I, [_P, _P, _P, _P, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P]),
     "r3g_tex_bake": (_I, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _I, _P, _P]),
+    "r3g_tex_bake_gather": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _P]),
     "r3g_tex_bake_finalize": (_I, [_P, _P, _I, _P, _P, _P]),
     "r3g_tex_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _I, ctypes.POINTER(_I), _P]),
     "r3g_model_create": (_I, [_P, _P]),

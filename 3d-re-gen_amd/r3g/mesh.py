@@ -237,7 +237,7 @@ def encode_png(img):
         return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
     raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * c)], axis=1).tobytes()
     return b"".join([b"\x89PNG\r\n\x1a\n", chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)),
-                     chunk(b"IDAT", zlib.compress(raw, 6)), chunk(b"IEND", b"")])
+                     chunk(b"IDAT", zlib.compress(raw, 6 if h * w <= 512 * 512 else 1)), chunk(b"IEND", b"")])
 
 
 def load_glb(data):

@@ -84,6 +84,26 @@ def bake(image, weight, findices, bary, uv, uv_tri, acc):
     return acc
 
 
+def bake_gather(findices_uv, bary_uv, clip_uv, uv_tri, image, weight, findices, depth, acc, depth_eps=0.01):
+    """texel-centric baking of one view into `acc`: clip_uv float32 [Vuv, 4] = this view's clip coordinates of the UV
+    vertices, depth float32 [H, W] = interpolate() of clip z / w over the view"""
+    fu = _dev(findices_uv, torch.int32, "findices_uv")
+    bu = _dev(bary_uv, torch.float32, "bary_uv")
+    cu = _dev(clip_uv, torch.float32, "clip_uv")
+    ut = _dev(uv_tri, torch.int32, "uv_tri")
+    img = _dev(image, torch.float32, "image")
+    w = _dev(weight, torch.float32, "weight")
+    fi = _dev(findices, torch.int32, "findices")
+    d = _dev(depth, torch.float32, "depth")
+    if not (acc.is_cuda and acc.dtype == torch.int64 and acc.is_contiguous() and acc.shape[0] == fu.shape[0]):
+        raise ValueError("acc must come from new_accumulator() of the UV raster's size")
+    h, wd = fi.shape
+    with torch.cuda.device(img.device):
+        ffi.check(ffi.lib().r3g_tex_bake_gather(ffi.context(img.device.index or 0), _p(fu), _p(bu), _p(cu), _p(ut), int(fu.shape[0]),
+                                                _p(img), _p(w), _p(fi), _p(d), int(h), int(wd), float(depth_eps), _p(acc), _s()))
+    return acc
+
+
 def bake_finalize(acc):
     """-> texture float32 [T, T, 3], mask uint8 [T, T] (1 where some view painted the texel)"""
     t = int(acc.shape[0])

@@ -183,7 +183,7 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
                 raise
             print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
             results.append((i, image_paths[i], "error: %s" % e, time.time() - t0))
-    return results, getattr(texgen, "implemented", True)
+    return results, texture_state(texgen)
 
 
 def run_distributed(config, input_folder, output_folder, rank, world, factory):
@@ -228,16 +228,18 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
         if getattr(mesh, "_dv", None) is not None:
             local.append((i, mesh._dv, mesh._df))          # still in HBM: goes over RCCL from there
         else:
-            local.append((i, np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32)))
+            local.append((i, np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32),
+                          getattr(mesh, "uv", None), getattr(mesh, "texture", None)))     # textured: uv + PNG source pixels too
     gathered = rdist.gather_meshes(local, dst=0)
     all_status = [None] * world
     dist.all_gather_object(all_status, status)
     if rank != 0:
         return None, None
     for i in sorted(gathered):
-        v, f = gathered[i]
-        export_mesh(Mesh(v, f), os.path.splitext(os.path.basename(image_paths[i]))[0], output_folder)
-    return sorted(r for part in all_status for r in part), getattr(texgen, "implemented", True)
+        g = gathered[i]
+        mesh = Mesh(g[0], g[1]) if len(g) == 2 else Mesh(g[0], g[1], uv=g[2], texture=g[3])
+        export_mesh(mesh, os.path.splitext(os.path.basename(image_paths[i]))[0], output_folder)
+    return sorted(r for part in all_status for r in part), texture_state(texgen)
 
 
 def main(argv=None, factory=default_factory):
@@ -293,12 +295,22 @@ def main(argv=None, factory=default_factory):
     return rc
 
 
+def texture_state(texgen):
+    """(textured, where the colours come from) of a texgen pipeline object"""
+    return bool(getattr(texgen, "implemented", True)), getattr(texgen, "source", None)
+
+
 def report(results, textured=True):
+    source = None
+    if isinstance(textured, tuple):
+        textured, source = textured
     ok = sum(1 for r in results if r[2] == "ok")
     rep = {"stage": "Hunyuan_2d_to_3d", "objects": len(results), "ok": ok,
            "failed": [os.path.basename(r[1]) for r in results if r[2] != "ok"],
            "seconds": [round(r[3], 3) for r in results],
            "textured": bool(textured)}
+    if source:
+        rep["texture_source"] = source
     if results and len(results[0]) > 4:
         rep["rank_of_object"] = [r[4] for r in results]
     print(json.dumps(rep))
@@ -306,16 +318,19 @@ def report(results, textured=True):
 
 
 def finish(rep, config):
-    """exit code of the stage.  The texture stage (hy3dgen.texgen) is not implemented on this path yet: the GLBs carry
-    geometry only.  That is reported (`"textured": false`) and warned about; `r3g_require_textures: true` in the config
-    turns it into a failure so that a pipeline that needs base-colour textures does not silently run on without them."""
+    """exit code of the stage.  GLBs without a base-colour texture (a texgen object with `implemented = False`) are
+    reported (`"textured": false`) and warned about; `r3g_require_textures: true` in the config turns that into a failure
+    so that a pipeline that needs textures does not silently run on without them.  When the texture does not come from
+    the multiview diffusion upstream uses (this path has no such model), `texture_source` says where it comes from."""
     if not rep["textured"]:
-        msg = ("[r3g] WARNING: the texture stage is not implemented on the MI355X path: %d GLB(s) written WITHOUT "
-               "baseColorTexture (geometry only)" % rep["ok"])
+        msg = ("[r3g] WARNING: no texture stage on this run: %d GLB(s) written WITHOUT baseColorTexture (geometry only)"
+               % rep["ok"])
         print(msg, file=sys.stderr)
         if config.get("r3g_require_textures", False):
             print("[r3g] r3g_require_textures is set: failing the stage", file=sys.stderr)
             return 3
+    elif rep.get("texture_source"):
+        print("[r3g] textures: %s" % rep["texture_source"], file=sys.stderr)
     return 0
 
 

@@ -117,6 +117,11 @@ int r3g_mesh_cluster_faces(r3g_ctx* ctx, float* d_verts, int64_t* n_verts, int32
  *                   the silhouette and where the depth jumps by more than depth_edge between 4-neighbours.
  *   bake          scatters a view (image float32 [H][W][3] in [0,1]) into acc uint64 [T][T][4] (zero it first; fixed point,
  *                   integer atomics: exact, order independent); texel = round(uv * (T-1)), v = 0 is the top row.
+ *   bake_gather   the same accumulation, texel-centric (what hy3dgen.texgen uses): every texel covered in findices_uv /
+ *                   bary_uv (= rasterize() of the mesh in UV space) interpolates its clip position from clip_uv float32
+ *                   [Vuv][4] (this view's clip coordinates of the UV vertices), must not lie behind the view's depth
+ *                   buffer (depth float32 [H][W] = interpolate() of clip z/w; tolerance depth_eps), takes the weight of the
+ *                   pixel it falls into and a bilinear sample of the image.  No atomics; texture as dense as the UV raster.
  *   bake_finalize acc -> texture float32 [T][T][3], mask uint8 [T][T] (1 = painted).
  *   inpaint       ~ mesh_processor.meshVerticeInpaint + the dilation upstream does with cv2: vertex colours from painted
  *                   texels, propagation along mesh edges (weights 1/(d^2 + 1e-6), Jacobi rounds until nothing changes),
@@ -131,6 +136,10 @@ int r3g_tex_view_weight(r3g_ctx* ctx, const int32_t* d_findices, const float* d_
                         void* stream);
 int r3g_tex_bake(r3g_ctx* ctx, const float* d_image, const float* d_weight, const int32_t* d_findices, const float* d_bary,
                  const float* d_uv, const int32_t* d_uv_tri, int64_t n_pixels, int tex_size, uint64_t* d_acc, void* stream);
+int r3g_tex_bake_gather(r3g_ctx* ctx, const int32_t* d_findices_uv, const float* d_bary_uv, const float* d_clip_uv,
+                        const int32_t* d_uv_tri, int tex_size, const float* d_image, const float* d_weight,
+                        const int32_t* d_findices, const float* d_depth, int height, int width, float depth_eps, uint64_t* d_acc,
+                        void* stream);
 int r3g_tex_bake_finalize(r3g_ctx* ctx, const uint64_t* d_acc, int tex_size, float* d_texture, uint8_t* d_mask, void* stream);
 int r3g_tex_inpaint(r3g_ctx* ctx, float* d_texture, uint8_t* d_mask, int tex_size, const int32_t* d_findices_uv,
                     const float* d_bary_uv, const float* d_verts, int64_t n_verts, const int32_t* d_pos_tri, const float* d_uv,

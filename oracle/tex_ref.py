@@ -145,6 +145,50 @@ def bake(image, weight, findices, bary, uv, uv_tri, T, acc=None):
     return acc
 
 
+def bake_gather(findices_uv, bary_uv, clip_uv, uv_tri, image, weight, findices, depth, depth_eps, acc=None):
+    """texel-centric baking of one view (see include/r3g.h bake_gather); accumulates into acc uint64 [T, T, 4]"""
+    T = findices_uv.shape[0]
+    H, W = findices.shape
+    acc = np.zeros((T, T, 4), np.uint64) if acc is None else acc
+    flat = acc.reshape(-1, 4)
+    fu = findices_uv.reshape(-1).astype(np.int64)
+    idx = np.nonzero(fu > 0)[0]
+    if not len(idx):
+        return acc
+    t = np.asarray(uv_tri, np.int64).reshape(-1, 3)[fu[idx] - 1]
+    b = bary_uv.reshape(-1, 3).astype(F32)[idx]
+    c = np.asarray(clip_uv, F32)
+    p = b[:, 0:1] * c[t[:, 0]] + b[:, 1:2] * c[t[:, 1]] + b[:, 2:3] * c[t[:, 2]]
+    with np.errstate(all="ignore"):
+        sx = (p[:, 0] / p[:, 3] * F32(0.5) + F32(0.5)) * F32(W - 1) + F32(0.5)
+        sy = (p[:, 1] / p[:, 3] * F32(0.5) + F32(0.5)) * F32(H - 1) + F32(0.5)
+        z = p[:, 2] / p[:, 3]
+    px, py = np.floor(sx), np.floor(sy)
+    ok = (p[:, 3] > 0) & (px >= 0) & (py >= 0) & (px < W) & (py < H)
+    idx, sx, sy, z = idx[ok], sx[ok], sy[ok], z[ok]
+    pix = py[ok].astype(np.int64) * W + px[ok].astype(np.int64)
+    w = weight.reshape(-1).astype(F32)[pix]
+    vis = (findices.reshape(-1)[pix] > 0) & (w > 0) & ~(z > depth.reshape(-1).astype(F32)[pix] + F32(depth_eps))
+    idx, sx, sy, w = idx[vis], sx[vis], sy[vis], w[vis]
+    wq = (np.minimum(w, F32(65535)) * F32(65536) + F32(0.5)).astype(np.uint64)
+    nz = wq > 0
+    idx, sx, sy, wq = idx[nz], sx[nz], sy[nz], wq[nz]
+    fx, fy = sx - F32(0.5), sy - F32(0.5)
+    x0f, y0f = np.floor(fx), np.floor(fy)
+    ax, ay = (fx - x0f).astype(F32), (fy - y0f).astype(F32)
+    x0, y0 = x0f.astype(np.int64), y0f.astype(np.int64)
+    x1, y1 = np.clip(x0 + 1, 0, W - 1), np.clip(y0 + 1, 0, H - 1)
+    x0, y0 = np.clip(x0, 0, W - 1), np.clip(y0, 0, H - 1)
+    img = image.astype(F32)
+    for ch in range(3):
+        c00, c01, c10, c11 = img[y0, x0, ch], img[y0, x1, ch], img[y1, x0, ch], img[y1, x1, ch]
+        top = c00 + (c01 - c00) * ax
+        bot = c10 + (c11 - c10) * ax
+        flat[idx, ch] += wq * _q16(top + (bot - top) * ay)
+    flat[idx, 3] += wq
+    return acc
+
+
 def bake_finalize(acc):
     w = acc[..., 3]
     with np.errstate(all="ignore"):

@@ -1,11 +1,12 @@
-"""TEST INFRASTRUCTURE: CPU stand-ins for the three places where the hy3dgen mirror touches the GPU, so that the
+"""TEST INFRASTRUCTURE: CPU stand-ins for the four places where the hy3dgen mirror touches the GPU, so that the
 reference's own stage script can be executed, unmodified, in the GPU-less build container (tests/test_reference_script.py).
 
 What stays the product's code on this run: the whole import surface of hy3dgen.{shapegen,texgen,rembg}, from_pretrained
 (snapshot directory, config.yaml, safetensors), ImageProcessorV2 / conditioner transform, the pipeline's __call__ (argument
 handling, CFG / scheduler plumbing, grid -> mesh), the Trimesh-like Mesh class, the cleaner classes' call surface, the GLB
 writer.  What is replaced: the device model (by the fp32 oracle), marching cubes (by the C oracle) and the mesh cleaners'
-kernels (by the numpy restatement / the host run of the edge-collapse code)."""
+kernels (by the numpy restatement / the host run of the edge-collapse code), and the texture-stage primitives of r3g.texops
+(by oracle/tex_ref.py; the texgen pipeline object, its view set-up, unwrap and image registration stay the product's)."""
 import contextlib
 
 import numpy as np
@@ -87,3 +88,45 @@ def install():
             self._df = torch.from_numpy(np.ascontiguousarray(self._f, np.int32))
         return self._dv, self._df
     rmesh.Mesh.device_buffers = device_buffers
+
+    # texture-stage primitives: numpy restatement behind the r3g.texops call surface, tensors on the host
+    from oracle import tex_ref
+    from r3g import texops
+    import hy3dgen.texgen.pipelines as tp
+
+    def n(t):
+        return t.detach().cpu().numpy()
+
+    def rasterize(pos_clip, tri, height, width):
+        fi, bary = tex_ref.rasterize(n(pos_clip), n(tri), height, width)
+        return torch.from_numpy(fi), torch.from_numpy(bary)
+    texops.rasterize = rasterize
+    texops.interpolate = lambda attr, tri, fi, bary: torch.from_numpy(tex_ref.interpolate(n(attr), n(tri), n(fi), n(bary)))
+    texops.view_weight = lambda fi, depth, normal, cos_threshold=0.1, depth_edge=0.01, view_weight=1.0, power=4.0: \
+        torch.from_numpy(tex_ref.view_weight(n(fi), n(depth), n(normal), cos_threshold, depth_edge, view_weight, power))
+    texops.new_accumulator = lambda tex_size, device: torch.zeros((tex_size, tex_size, 4), dtype=torch.int64)
+
+    def bake(image, weight, fi, bary, uv, uv_tri, acc):
+        a = n(acc).view(np.uint64)
+        tex_ref.bake(n(image), n(weight), n(fi), n(bary), n(uv), n(uv_tri), a.shape[0], a)
+        acc.copy_(torch.from_numpy(a.view(np.int64)))
+        return acc
+    texops.bake = bake
+
+    def bake_gather(fi_uv, bary_uv, clip_uv, uv_tri, image, weight, fi, depth, acc, depth_eps=0.01):
+        a = n(acc).view(np.uint64)
+        tex_ref.bake_gather(n(fi_uv), n(bary_uv), n(clip_uv), n(uv_tri), n(image), n(weight), n(fi), n(depth), depth_eps, a)
+        acc.copy_(torch.from_numpy(a.view(np.int64)))
+        return acc
+    texops.bake_gather = bake_gather
+
+    def bake_finalize(acc):
+        tex, mask = tex_ref.bake_finalize(n(acc).view(np.uint64))
+        return torch.from_numpy(tex), torch.from_numpy(mask)
+    texops.bake_finalize = bake_finalize
+
+    def inpaint(texture, mask, fi_uv, bary_uv, verts, pos_tri, uv, uv_tri, dilate_iters=8):
+        tex, m, rounds = tex_ref.inpaint(n(texture), n(mask), n(fi_uv), n(bary_uv), n(verts), n(pos_tri), n(uv), n(uv_tri), dilate_iters)
+        return torch.from_numpy(tex), torch.from_numpy(m), rounds
+    texops.inpaint = inpaint
+    tp.Hunyuan3DPaintPipeline._device = lambda self: torch.device("cpu")

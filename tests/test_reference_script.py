@@ -67,7 +67,8 @@ def test_reference_stage_script_runs_unmodified_against_the_mirror(tmp_path, rem
         os.path.join(REF, "src"), os.path.join(REF, "src", "utils"),    # as reference run.py:72-86 builds it
         pkg,                                           # where the orchestrator puts <root>/Hunyuan3D-2
         ROOT])                                         # the oracle package, for the stand-ins only
-    env.update(R3G_TEST_CPU_SHIM="1", R3G_TEST_SNAPSHOT=snap, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    env.update(R3G_TEST_CPU_SHIM="1", R3G_TEST_SNAPSHOT=snap, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="",
+               R3G_TEX_SIZE="192", R3G_TEX_RENDER="96")      # small texture: the stand-in rasteriser is numpy
     r = subprocess.run([sys.executable, SCRIPT, "--config", cpath], cwd=os.path.join(REF, "src"), env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -83,3 +84,8 @@ def test_reference_stage_script_runs_unmodified_against_the_mirror(tmp_path, rem
     if remesh:
         assert "Remeshing enabled" in r.stdout and m.n_faces <= 300
     assert "Saved chair__(10, 20)" in r.stdout
+    # the script's texgen call (reference run.py:97) produced a base-colour texture that an independent validator accepts
+    from gltf_validate import validate_glb
+    got = validate_glb(data)
+    assert got["image"] is not None and got["image"].shape[:2] == (192, 192)
+    assert "TEXCOORD_0" in got["attributes"] and len(got["attributes"]["TEXCOORD_0"]) == len(got["positions"])

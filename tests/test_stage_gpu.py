@@ -43,7 +43,9 @@ def test_stage_script_writes_glbs(tmp_path):
         from gltf_validate import validate_glb                     # independent glTF 2.0 checks (tests/gltf_validate.py)
         got = validate_glb((out / stem / (stem + ".glb")).read_bytes())
         assert np.array_equal(got["indices"].astype(np.int64), m.faces) and len(got["positions"]) == len(m.vertices)
+        assert got["image"] is not None and "TEXCOORD_0" in got["attributes"]      # texgen baked a base-colour texture
         assert np.isfinite(m.vertices).all() and np.abs(m.vertices).max() <= 1.02
+    assert rep["textured"] is True and "input view only" in rep["texture_source"]
 
 
 def test_octree_resolution_512_end_to_end():

@@ -85,6 +85,20 @@ def test_bake_two_views_and_inpaint_match_the_oracle():
         acc_ref = tex_ref.bake(img, w_ref, fi_ref, bary_ref, uv, uv_tri, T, acc_ref)
         texops.bake(_t(img), _t(w_ref), fi, bary, _t(uv), _t(uv_tri), acc)
     assert np.array_equal(acc.cpu().numpy().view(np.uint64), acc_ref)
+    # texel-centric baking of the same views (oracle weights on both sides: integer accumulators must agree exactly)
+    uvc = np.concatenate([uv * 2 - 1, np.zeros((len(uv), 1), np.float32), np.ones((len(uv), 1), np.float32)], 1)
+    fu_ref, bu_ref = tex_ref.rasterize(uvc, uv_tri, T, T)
+    fu, bu = texops.rasterize(_t(uvc), _t(uv_tri), T, T)
+    g_ref, g = None, texops.new_accumulator(T, "cuda")
+    for clip, nrm_v, img in scene:
+        fi_ref, bary_ref = tex_ref.rasterize(clip, f, R, R)
+        depth_ref = tex_ref.interpolate(clip[:, 2:3], f, fi_ref, bary_ref)[..., 0]
+        w_ref = tex_ref.view_weight(fi_ref, depth_ref, tex_ref.interpolate(nrm_v, f, fi_ref, bary_ref), 0.2, 0.05, 0.8, 3.0)
+        clip_uv = np.ascontiguousarray(clip[f].reshape(-1, 4))
+        g_ref = tex_ref.bake_gather(fu_ref, bu_ref, clip_uv, uv_tri, img, w_ref, fi_ref, depth_ref, 0.02, g_ref)
+        texops.bake_gather(fu, bu, _t(clip_uv), _t(uv_tri), _t(img), _t(w_ref), _t(fi_ref), _t(depth_ref), g, 0.02)
+    assert np.array_equal(g.cpu().numpy().view(np.uint64), g_ref)
+    assert 0.2 < (g_ref[..., 3] > 0).sum() / (fu_ref > 0).sum() < 0.9        # two views see part of the sphere, densely
     tex_ref_, mask_ref = tex_ref.bake_finalize(acc_ref)
     tex, mask = texops.bake_finalize(acc)
     assert np.array_equal(mask.cpu().numpy(), mask_ref) and np.array_equal(tex.cpu().numpy(), tex_ref_)
