@@ -243,6 +243,27 @@ def test_full_depth_dit_forward():
     assert torch.isfinite(out).all() and err <= TOL["dit_forward_full_depth"]
 
 
+def test_full_depth_conditioner_and_vae():
+    """DINOv2-giant at full width AND full depth (40 layers, 1370 tokens) against the real transformers.Dinov2Model the
+    oracle wraps, and the ShapeVAE transformer at its full 16 layers: the depths the 1-layer tests above do not reach."""
+    import torch
+    from oracle import hy3d_torch as H
+    s = Setup(H.wide_config(depth=1, depth_single=1, vae_layers=16, cond_layers=40), 23)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(3, 518, 518, generator=g)
+    with torch.no_grad():
+        ref = s.oracle.conditioner.main_image_encoder.model(img[None]).last_hidden_state[0]
+    err = rel_l2(s.gpu.cond_encode(img).float(), ref)
+    report("full-depth conditioner (40 layers, real Dinov2Model)", err, TOL["conditioner"])
+    assert err <= TOL["conditioner"]
+    lat = torch.randn(3072, 64, generator=g)
+    with torch.no_grad():
+        z_ref = s.oracle.vae(lat[None] / s.oracle.vae.scale_factor)
+    err = rel_l2(s.gpu.vae_decode(lat, return_z=True), z_ref[0])
+    report("full-depth vae latents (16 layers)", err, TOL["vae_latents"])
+    assert err <= TOL["vae_latents"]
+
+
 def test_full_width_conditioner_vae_and_grid_points(wide):
     import torch
     g = torch.Generator().manual_seed(3)
