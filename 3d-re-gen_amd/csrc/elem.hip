@@ -30,19 +30,32 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 // ---------------------------------------------------------------- LayerNorm (+affine) (+adaLN modulate) -> bf16
 constexpr int LN_MAX_V4 = 8;  // up to C = 64*4*8 = 2048
+// four consecutive elements of a row held as f32 (XBF16 = false) or bf16 (true)
+template <bool XBF16>
+__device__ __forceinline__ float4 load_row4(const float* base, int64_t elem) {
+    if constexpr (XBF16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(base + elem);
+    }
+}
+
+template <bool XBF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int batch = row / p.rows_per_batch, lrow = row - batch * p.rows_per_batch;
-    const float* x = p.x + (int64_t)batch * p.x_batch_stride + (int64_t)lrow * p.ldx;
+    const int64_t xrow = (int64_t)batch * p.x_batch_stride + (int64_t)lrow * p.ldx;
     const int nv = p.C >> 8;  // float4 per lane (C % 256 == 0) -- handled by launcher for other C via scalar path
     float4 v[LN_MAX_V4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (i < nv) {
-            v[i] = *reinterpret_cast<const float4*>(x + (i * 64 + lane) * 4);
+            v[i] = load_row4<XBF16>(p.x, xrow + (i * 64 + lane) * 4);
             s += v[i].x + v[i].y + v[i].z + v[i].w;
         }
     const float mean = wave_sum(s) / (float)p.C;
@@ -345,6 +358,7 @@ __global__ void fourier_grid_kernel(uint16_t* out, int64_t start, int count, int
     for (int c = dim; c < 64; ++c) o[c] = 0;
 }
 
+template <bool XBF16>
 __global__ __launch_bounds__(256) void ln_dot_kernel(const float* x, int64_t ldx, int rows, int C, int do_ln,
                                                      const float* lnw, const float* lnb, float eps, const float* w,
                                                      float b, float* out) {
@@ -352,14 +366,13 @@ __global__ __launch_bounds__(256) void ln_dot_kernel(const float* x, int64_t ldx
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (int64_t)row * ldx;
     const int nv = C >> 8;
     float4 v[LN_MAX_V4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (i < nv) {
-            v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+            v[i] = load_row4<XBF16>(x, (int64_t)row * ldx + (i * 64 + lane) * 4);
             s += v[i].x + v[i].y + v[i].z + v[i].w;
         }
     float mean = wave_sum(s) / (float)C;
@@ -450,8 +463,11 @@ hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;
     if (p.C % 64 || p.C > 2048) return hipErrorInvalidValue;
     ProfScope ps(PC_LAYERNORM, 6.0 * (double)p.rows * p.C, s);
-    if (p.C % 256 == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0) {
-        hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    if (p.x_bf16) {
+        if (p.C % 256 || (p.ldx & 3) || (p.ldy & 3) || (p.x_batch_stride & 3)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    } else if (p.C % 256 == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0) {
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL(layernorm_small_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     }
@@ -529,10 +545,14 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
 }
 
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb,
-                         float eps, const float* w, float b, float* out, hipStream_t s) {
+                         float eps, const float* w, float b, float* out, hipStream_t s, int x_bf16) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
-    if (C % 256 == 0 && C <= 2048 && (ldx & 3) == 0) {
-        hipLaunchKernelGGL(ln_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w,
+    if (x_bf16) {
+        if (C % 256 || C > 2048 || (ldx & 3)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ln_dot_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps,
+                           w, b, out);
+    } else if (C % 256 == 0 && C <= 2048 && (ldx & 3) == 0) {
+        hipLaunchKernelGGL(ln_dot_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w,
                            b, out);
     } else {
         hipLaunchKernelGGL(ln_dot_small_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb,

@@ -297,6 +297,91 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     const int mrow = m0 + wr * WROWS + (lane & 15);
     const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
     const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
+    if constexpr (EPI == EPI_RESID_BF16) {
+        // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
+        uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
+        f32x4 bj[4], gj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = ncol + j * 16;
+            const int nbc = nb < p.N ? nb : p.N - 4;
+            bj[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gj[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (p.bias) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + nbc);
+            if (gate) gj[j] = *reinterpret_cast<const f32x4*>(gate + nbc);
+        }
+        const bool wide = lds_wave != nullptr && PI >= 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0 &&
+                          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+        if (wide) {
+            // passes of RP rows x 64 columns of fp32 through the wave's scratch (256-byte rows, 16-byte chunks swizzled by
+            // the row); the read side owns 8 consecutive columns of a row: one 16-byte load of the old values, one
+            // 16-byte store -- 8 rows x 128 contiguous bytes per instruction, whole cache lines both ways
+            constexpr int RP = PI * 8;          // rows per pass (PI * 16 rows x 128 B of scratch = RP rows x 256 B)
+            constexpr int GP = PI / 2;          // 16-row groups per pass
+            const int cc = lane & 7;
+            const int n = n0 + wc * 64 + cc * 8;
+#pragma unroll
+            for (int ip = 0; ip < MI; ip += GP) {
+                uint4 old[RP / 8];
+#pragma unroll
+                for (int t = 0; t < RP / 8; ++t) {
+                    const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
+                    const int mc = m < p.M ? m : p.M - 1;
+                    const int nc = n < p.N ? n : p.N - 8;
+                    old[t] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * p.ldc + nc);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < GP; ++ii) {
+                        const int r = ii * 16 + (lane & 15);
+                        const int chunk = (j * 4 + (lane >> 4)) ^ (r & 15);
+                        *reinterpret_cast<f32x4*>(lds_wave + r * 256 + chunk * 16) = gj[j] * (acc[j][ip + ii] + bj[j]);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < RP / 8; ++t) {
+                    const int rr = t * 8 + (lane >> 3);
+                    const int m = m0 + wr * WROWS + ip * 16 + rr;
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(lds_wave + rr * 256 + (((2 * cc) ^ (rr & 15)) << 4));
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(lds_wave + rr * 256 + (((2 * cc + 1) ^ (rr & 15)) << 4));
+                    const uint32_t o[4] = {old[t].x, old[t].y, old[t].z, old[t].w};
+                    uint32_t q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(o[k] << 16), hi = __uint_as_float(o[k] & 0xFFFF0000u);
+                        const f32x4& d = k < 2 ? d0 : d1;
+                        q[k] = pack_bf16(lo + d[(k & 1) * 2], hi + d[(k & 1) * 2 + 1]);
+                    }
+                    if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint2 old[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
+                old[i] = *reinterpret_cast<const uint2*>(X + (int64_t)mc * p.ldc + nc);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int n = ncol + j * 16, m = mrow + i * 16;
+                const f32x4 d = gj[j] * (acc[j][i] + bj[j]);
+                uint2 pk;
+                pk.x = pack_bf16(__uint_as_float(old[i].x << 16) + d[0], __uint_as_float(old[i].x & 0xFFFF0000u) + d[1]);
+                pk.y = pack_bf16(__uint_as_float(old[i].y << 16) + d[2], __uint_as_float(old[i].y & 0xFFFF0000u) + d[3]);
+                if (n < p.N && m < p.M) *reinterpret_cast<uint2*>(X + (int64_t)m * p.ldc + n) = pk;
+            }
+        }
+        return;
+    }
     if constexpr (EPI == EPI_RESID_F32) {
         float* X = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.strideC;
         const bool wide = lds_wave != nullptr && (p.ldc & 3) == 0 && (p.strideC & 3) == 0 &&
@@ -1235,7 +1320,7 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
             if (p2.M > 0) tiles += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
             if (p.K >= 256 && (p2.M == 0 || p2.K >= 256) &&
-                (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && EPI != EPI_RESID_F32 && EPI != EPI_F32))) {
+                (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && EPI != EPI_RESID_F32 && EPI != EPI_RESID_BF16 && EPI != EPI_F32))) {
                 const hipError_t e = launch_gemm8p<EPI>(p, p2, g_num_cu, s);
                 if (e != hipErrorNotSupported) return e;
             }
@@ -1293,7 +1378,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     // algorithmic bytes of a launch: each operand read once, the result written once (fp32 residual: read + written)
     auto alg_bytes = [](const GemmArgs& g) {
         if (g.M <= 0) return 0.0;
-        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 ? 4.0 : 2.0);
+        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 ? 4.0 : 2.0);
         return (double)g.batch * (2.0 * g.M * g.K + out * (double)g.M * g.N) + 2.0 * (double)g.N * g.K;
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
@@ -1305,6 +1390,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
         case EPI_RESID_F32: return launch_epi<EPI_RESID_F32>(p, p2, g_gemm_glds, s);
         case EPI_F32: return launch_epi<EPI_F32>(p, p2, g_gemm_glds, s);
         case EPI_QKV: return launch_epi<EPI_QKV>(p, p2, g_gemm_glds, s);
+        case EPI_RESID_BF16: return launch_epi<EPI_RESID_BF16>(p, p2, g_gemm_glds, s);
         default: return hipErrorInvalidValue;
     }
 }

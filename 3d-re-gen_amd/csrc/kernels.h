@@ -14,6 +14,7 @@ enum GemmEpilogue {
     EPI_RESID_F32 = 3,       // C(f32) += gate[b][n] * (acc + bias)      (gate null -> 1)
     EPI_F32 = 4,             // C(f32) = acc + bias
     EPI_QKV = 5,             // split into attention operands: per-head q/k norm, Q/K [B][H][L][64], V^T [B][H][64][L]
+    EPI_RESID_BF16 = 6,      // C(bf16) = bf16(C + gate[b][n] * (acc + bias)): a 16-bit residual stream (sum formed in fp32)
 };
 
 enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
@@ -113,7 +114,8 @@ void attn_set_generation(int gen);   // 2 (default) | 1: the first-round kernel 
 // ------------------------------------------------------------------ elementwise / norms (elem.hip)
 // y(bf16)[r][c] = ((x - mean) * rstd * (w ? w[c] : 1) + (b ? b[c] : 0)) * (1 + scale[batch][c]) + shift[batch][c]
 struct LnArgs {
-    const float* x; int64_t ldx;        // f32 [rows][C]
+    const float* x; int64_t ldx;        // f32 [rows][C] (bf16 [rows][C] behind the same pointer when x_bf16 != 0)
+    int x_bf16;
     uint16_t* y; int64_t ldy;           // bf16 [rows][C]
     int64_t x_batch_stride, y_batch_stride;  // row r lives at batch (r / rows_per_batch), local row r % rows_per_batch
     const float* w; const float* b;     // affine [C] or null
@@ -169,7 +171,7 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
                                int include_pi, hipStream_t s);
 // logits[r] = LN(x[r]) . w + b  (ln_post + output_proj fused);  x f32 [rows][C]
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb, float eps,
-                         const float* w, float b, float* out, hipStream_t s);
+                         const float* w, float b, float* out, hipStream_t s, int x_bf16 = 0);
 // DINOv2 patch embedding im2col: image f32 [3][S][S] -> bf16 [P*P][Kpad], K = 3*ps*ps ordered (c, dy, dx)
 hipError_t im2col_launch(const float* img, int S, int ps, uint16_t* out, int Kpad, hipStream_t s);
 // x(f32)[r][c] = a(f32)[r][c] (+ pos[r][c]) ; assorted small helpers

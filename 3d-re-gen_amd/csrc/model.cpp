@@ -49,6 +49,7 @@ static bool g_overlap_mlp = true;     // single blocks: MLP-in GEMM on a second 
 static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
+static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
 
 struct Model {
@@ -197,9 +198,9 @@ static int gemm_qkv(Model& m, const uint16_t* A, int64_t lda, int64_t strideA, c
 
 static int layernorm(const float* x, int64_t ldx, int64_t xbs, uint16_t* y, int64_t ldy, int64_t ybs, int rows_per_batch,
                      int batch, int C, const float* w, const float* b, const float* scale, const float* shift,
-                     int64_t mod_stride, float eps, hipStream_t s) {
+                     int64_t mod_stride, float eps, hipStream_t s, int x_bf16 = 0) {
     LnArgs p{};
-    p.x = x; p.ldx = ldx; p.x_batch_stride = xbs;
+    p.x = x; p.ldx = ldx; p.x_batch_stride = xbs; p.x_bf16 = x_bf16;
     p.y = y; p.ldy = ldy; p.y_batch_stride = ybs;
     p.w = w; p.b = b; p.scale = scale; p.shift = shift; p.mod_stride = mod_stride;
     p.rows = rows_per_batch * batch; p.C = C; p.rows_per_batch = rows_per_batch; p.eps = eps;
@@ -644,8 +645,12 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         const int n = (int)std::min<int64_t>(m.qc, count - off);
         const int npad = (int)rup(n, 128);
         R3G_TRY(fourier_grid_launch(m.inb, start + off, npad, R, bound, c.vae_num_freqs, c.vae_include_pi, s));
-        R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, EPI_F32, nullptr, 0, 1, s));
-        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s));
+        // residual stream of the decoder block: fp32 (round 1) or, by default, bf16 -- the reference keeps it in fp16; it is
+        // read / written 7 times per point, 0.9 TB per object in fp32.  The bf16 stream lives in the same buffer (m.f32a).
+        const int xb = g_geo_resid_bf16 && W % 256 == 0 ? 1 : 0;
+        const int epi_x0 = xb ? EPI_BF16 : EPI_F32, epi_res = xb ? EPI_RESID_BF16 : EPI_RESID_F32;
+        R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, epi_x0, nullptr, 0, 1, s));
+        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
@@ -658,11 +663,11 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         }
         R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
         R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
-        R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, EPI_RESID_F32, nullptr, 0, 1, s));
-        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s));
+        R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0, 1, s));
+        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
         R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
-        R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, EPI_RESID_F32, nullptr, 0, 1, s));
-        R3G_TRY(ln_dot_launch(m.f32a, W, n, W, c.vae_ln_post, lpw, lpb, 1e-5f, ow, ob, grid + start + off, s));
+        R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, epi_res, nullptr, 0, 1, s));
+        R3G_TRY(ln_dot_launch(m.f32a, W, n, W, c.vae_ln_post, lpw, lpb, 1e-5f, ow, ob, grid + start + off, s, xb));
     }
     return R3G_OK;
 }
@@ -943,6 +948,7 @@ int r3g_set_option(const char* name, int value) {
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
+    else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);

@@ -74,6 +74,32 @@ def test_gemm_epilogues(env, epi):
     assert rel_l2(c.float(), ref) <= 5e-3
 
 
+@pytest.mark.parametrize("variant", [0, 8, 9, 11, 12])
+@pytest.mark.parametrize("M,N,K", [(515, 768, 1024), (1024, 1024, 256), (77, 256, 128)])
+def test_gemm_bf16_residual_epilogue(env, variant, M, N, K):
+    """EPI_RESID_BF16: c(bf16) = bf16(c + gate * (a w^T + bias)), the sum in fp32, on every tile kernel (wide LDS path, ragged
+    edges, persistent grid); the old values must be read before they are overwritten."""
+    torch, L, ffi = env
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    gate = torch.randn(N, device="cuda", generator=g)
+    c0 = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    c = c0.clone()
+    want = (c0.float() + gate * (a.float() @ w.float().t() + bias)).to(torch.bfloat16)
+    try:
+        ffi.check(L.r3g_set_option(b"gemm_waves", variant))
+        ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N, gate.data_ptr(), M, N, K, 6,
+                                1, stream(torch)))
+    finally:
+        ffi.check(L.r3g_set_option(b"gemm_waves", 0))
+    assert rel_l2(c.float(), want.float()) <= 4e-3
+    # one bf16 step at most, almost everywhere identical (the kernel's k order differs from torch's)
+    ulp = (c.float() - want.float()).abs() / want.float().abs().clamp_min(1e-3)
+    assert float(ulp.max()) <= 2 ** -6 and float((ulp > 0).float().mean()) < 0.2
+
+
 def test_gemm_strided_views(env):
     """column slab of a wider weight (ldw > K) and of wider activations / outputs (lda, ldc > width)"""
     torch, L, ffi = env

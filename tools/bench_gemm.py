@@ -27,6 +27,8 @@ SHAPES = {
             (7552, 1024, 1024, 3), (7552, 7168, 1024, 0)],
     # ... and of one 131072-point pass of the geo decoder
     "geo": [(131072, 1024, 1024, 0), (131072, 1024, 1024, 3), (131072, 4096, 1024, 2), (131072, 1024, 4096, 3)],
+    # the geo decoder's residual GEMMs with the 16-bit residual stream
+    "geo16": [(131072, 1024, 1024, 6), (131072, 1024, 4096, 6), (131072, 1024, 1024, 3), (131072, 1024, 4096, 3)],
     # K sweep at the geo decoder's M: intercept = fixed cost per tile round (prologue + epilogue), slope = cost per k
     "ksweep": [(131072, 1024, k, e) for e in (0, 3) for k in (128, 256, 512, 1024, 2048)],
     # ragged edges for the screen
@@ -41,7 +43,9 @@ def make(M, N, K, epi, seed):
     w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda", generator=g)
     gate = torch.randn(N, device="cuda", generator=g)
-    c0 = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
+    c0 = torch.randn(M, N, device="cuda", generator=g) if epi in (3, 6) else None
+    if epi == 6:
+        c0 = c0.to(torch.bfloat16)
     return a, w, bias, gate, c0
 
 
@@ -62,15 +66,15 @@ def main():
     def run(v, a, w, bias, gate, c, M, N, K, epi):
         ffi.check(L.r3g_set_option(b"gemm_waves", v))
         ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
-                                gate.data_ptr() if epi == 3 else None, M, N, K, epi, 1, s))
+                                gate.data_ptr() if epi in (3, 6) else None, M, N, K, epi, 1, s))
 
     for group in a_.shapes.split(","):
         for (M, N, K, epi) in SHAPES[group]:
             a, w, bias, gate, c0 = make(M, N, K, epi, M + N + K + epi)
-            dt = torch.float32 if epi >= 3 else torch.bfloat16
+            dt = torch.float32 if epi in (3, 4) else torch.bfloat16
 
             def fresh():
-                return c0.clone() if epi == 3 else torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+                return c0.clone() if epi in (3, 6) else torch.full((M, N), float("nan"), device="cuda", dtype=dt)
             ref = fresh()
             run(8, a, w, bias, gate, ref, M, N, K, epi)
             lin = a.float() @ w.float().t() + bias
@@ -78,8 +82,8 @@ def main():
                 want = torch.nn.functional.gelu(lin, approximate="tanh")
             elif epi == 2:
                 want = torch.nn.functional.gelu(lin)
-            elif epi == 3:
-                want = c0 + gate * lin
+            elif epi in (3, 6):
+                want = c0.float() + gate * lin
             else:
                 want = lin
             rel = float(torch.linalg.norm(ref.float() - want) / torch.linalg.norm(want))
