@@ -783,8 +783,16 @@ __global__ __launch_bounds__(512) void gemm_deep_kernel(GemmArgs p) {
 #define R3G_BAR() asm volatile("s_barrier" ::: "memory")
 #define R3G_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
+// SPLIT: deterministic split-K over two workgroups per tile (for launches whose 256x256 tiles fill less than half of the
+// CUs, i.e. the N = 1024 residual GEMMs of the DiT: 120 tiles).  Workgroup s of a tile runs k-tiles [s nk/2, (s+1) nk/2),
+// hands the accumulators of the OTHER wave row (tile rows 128 (1 - s) ...) to its partner through a workspace, waits for
+// the partner's accumulators of its own wave row, adds them (two addends: the sum does not depend on the order) and runs
+// the epilogue for its 128 rows with its four waves.  Flags carry the launch's epoch (never reset); data and flags move
+// with device-scope (sc1) stores and loads, the flag after the wave's data stores have been acknowledged.  Both workgroups of a tile must be resident at once: the
+// launcher only takes this path when the whole grid fits the CUs at one workgroup each.
+template <int EPI, bool SPLIT = false>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb, float* split_ws, unsigned* split_flags,
+                                                    unsigned split_epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, MI = 8;
     constexpr int HALF = 16384, BUF = 4 * HALF;   // buffer: [A_0][A_1][W_0][W_1]
@@ -792,7 +800,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int wg_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // split: consecutive workgroups (same XCD, same L2) are the two halves of one tile
+    const int wg_all = SPLIT ? wg_lin >> 1 : wg_lin;
+    const int ksplit = SPLIT ? (wg_lin & 1) : 0;
     const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
     const bool second = wg_all >= tiles_a;
     typedef const char __attribute__((address_space(4))) * kernarg_ptr;
@@ -831,8 +842,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
                 int gw = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
                 ga = ga < p.M ? ga : p.M - 1;
                 gw = gw < p.N ? gw : p.N - 1;
-                srcA[h][i] = A + (int64_t)ga * p.lda + kc * 8;
-                srcW[h][i] = p.W + (int64_t)gw * p.ldw + kc * 8;
+                const int k0 = SPLIT ? ksplit * (p.K / 2) : 0;
+                srcA[h][i] = A + (int64_t)ga * p.lda + kc * 8 + k0;
+                srcW[h][i] = p.W + (int64_t)gw * p.ldw + kc * 8 + k0;
             }
         }
     }
@@ -906,7 +918,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    const int nk = p.K / BK;   // even, >= 2 (checked by the launcher)
+    const int nk = (SPLIT ? p.K / 2 : p.K) / BK;   // even, >= 2 (checked by the launcher)
     stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
     stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -971,6 +983,48 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb) {
     four_phases(I1{}, std::false_type{}, t + 1);
     if (wr == 0) R3G_BAR();
 
+    if constexpr (SPLIT) {
+        // [tile][receiving half][wave column][register group of 4][lane] f32x4: 1 KiB per wave instruction.
+        // The exchange uses DEVICE-scope accesses (sc1: stores write through to the memory side, loads do not trust a
+        // possibly stale L2 line of another XCD) and no cache-wide fence: an agent-scope release fence writes back the
+        // whole L2 (buffer_wbl2) -- measured +100 us per launch with 960 waves doing it.
+        const size_t slot = ((size_t)wg_all * 2) * 4 * 32 * 64;
+        if (wr != ksplit) {
+            f32x4* dst = reinterpret_cast<f32x4*>(split_ws) + slot + ((size_t)(wr * 4 + wc) * 32) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (size_t)(j * MI + i) * 64), "v"(acc[j][i]) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this wave has been performed at device scope
+            if (lane == 0) {
+                unsigned* flag = &split_flags[(wg_all * 2 + wr) * 4 + wc];
+                asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(flag), "v"(split_epoch) : "memory");
+            }
+            return;
+        }
+        {
+            const unsigned* flag = &split_flags[(wg_all * 2 + wr) * 4 + wc];
+            unsigned spins = 0, seen;
+            do {
+                asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(flag) : "memory");
+                seen = __builtin_amdgcn_readfirstlane(seen);
+                if (seen == split_epoch) break;
+                __builtin_amdgcn_s_sleep(4);
+            } while (++spins < (1u << 24));   // never hang the device: a lost partner shows up as a wrong result
+            const f32x4* src = reinterpret_cast<const f32x4*>(split_ws) + slot + ((size_t)(wr * 4 + wc) * 32) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 t[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i]) : "v"(src + (size_t)(j * MI + i) * 64) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[j][i] += t[i];
+            }
+        }
+    }
     gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
 }
 
@@ -1234,13 +1288,45 @@ hipError_t launch_gemm8(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
     int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
     if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
     const size_t lds = 131072;
-    auto k = gemm8_kernel<EPI>;
+    auto k = gemm8_kernel<EPI, false>;
     static bool done = false;
     if (!done) {
         done = true;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p, p2);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p, p2, (float*)nullptr, (unsigned*)nullptr, 0u);
+    return hipGetLastError();
+}
+
+// split-K workspace: one slot of 256 KiB + 8 flags per tile, for at most kSplitMaxTiles tiles; one launch at a time may use
+// it (the launches that take this path are all on the model's main stream)
+constexpr int kSplitMaxTiles = 128;
+static float* g_split_ws = nullptr;
+static unsigned* g_split_flags = nullptr;
+static unsigned g_split_epoch = 0;
+
+template <int EPI>
+hipError_t launch_gemm8_split(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
+    int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+    if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+    if (tiles > kSplitMaxTiles) return hipErrorNotSupported;
+    if (!g_split_ws) {
+        hipError_t e = hipMalloc((void**)&g_split_ws, (size_t)kSplitMaxTiles * 256 * 256 * 4);
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&g_split_flags, (size_t)kSplitMaxTiles * 8 * 4);
+        if (e != hipSuccess) return e;
+        e = hipMemset(g_split_flags, 0, (size_t)kSplitMaxTiles * 8 * 4);
+        if (e != hipSuccess) return e;
+    }
+    const size_t lds = 131072;
+    auto k = gemm8_kernel<EPI, true>;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (++g_split_epoch == 0u) g_split_epoch = 1u;   // 0 is the flags' initial value
+    hipLaunchKernelGGL(k, dim3(2 * tiles), dim3(512), lds, s, p, p2, g_split_ws, g_split_flags, g_split_epoch);
     return hipGetLastError();
 }
 
@@ -1285,6 +1371,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 1, g_num_cu = 256;
+bool g_gemm_splitk = false;      // deterministic split-K for deep-K residual GEMMs on under-filled grids (measured: no gain)
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
@@ -1313,6 +1400,21 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             else waves = 8;
         }
     }
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_BF16 || EPI == EPI_BF16) {
+        // deterministic split-K over 256x256 tiles (waves == 13 forces it): a deep K on a grid that fills less than half
+        // of the CUs with 256x256 tiles and would otherwise run 128x128 tiles at 2.4x the operand traffic
+        long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+        if (p2.M > 0) tiles += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+        const bool shape_ok = p.K % 256 == 0 && p.K >= 512 && (p2.M == 0 || p2.K == p.K) && p.N % 256 == 0 &&
+                              (p2.M == 0 || p2.N % 256 == 0) && 2 * tiles <= g_num_cu && tiles <= kSplitMaxTiles;
+        if (shape_ok && (waves == 13 || (g_gemm_splitk && g_gemm_waves == 0 && EPI == EPI_RESID_F32 && p.K >= 2048 &&
+                                         2 * tiles > g_num_cu / 2))) {
+            const hipError_t e = launch_gemm8_split<EPI>(p, p2, s);
+            if (e != hipErrorNotSupported) return e;
+        }
+        if (waves == 13) waves = 11;
+    }
+    if (waves == 13) waves = 11;
     if ((waves == 11 || waves == 12) && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) {   // phased 256x256x64
         if constexpr (EPI != EPI_QKV) {
             // persistent form when a CU gets more than one tile and the output is bf16 (waves == 12 forces it for any
@@ -1348,8 +1450,9 @@ void gemm_set_auto_rule(int rule, int num_cu) {
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
+void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
 void gemm_set_config(int waves, int stages) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;
     if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 

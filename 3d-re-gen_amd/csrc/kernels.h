@@ -77,6 +77,7 @@ void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off b
 void gemm_set_config(int waves, int stages);
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
+void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs
 void gemm_set_persistent(bool on);   // phased kernel walks several tiles per workgroup (default on)
 void gemm_set_phased(bool on);   // 256x256 tiles: phased kernel (default) or the two-stage one
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages

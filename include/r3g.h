@@ -238,7 +238,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
  * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 two-stage | 10 = 256x128 | 11 = 256x256 phased | 12 = phased,
- * persistent grid | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"
+ * persistent grid | 13 = phased, deterministic split-K over two workgroups per tile | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"
  * (1: 256x256 tiles on the phased counted-vmcnt kernel), "gemm_persistent" (1: its persistent form for bf16 outputs
  * with more tiles than CUs), "gemm_num_cu" (CUs the tile rules assume, default 256), "attn_generation" (2 default |
  * 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_pipelined" (0), "attn_ablate"

@@ -100,6 +100,40 @@ def test_gemm_bf16_residual_epilogue(env, variant, M, N, K):
     assert float(ulp.max()) <= 2 ** -6 and float((ulp > 0).float().mean()) < 0.2
 
 
+@pytest.mark.parametrize("epi", [3, 6, 0])
+@pytest.mark.parametrize("M,N,K", [(7552, 1024, 5120), (1000, 512, 512), (256, 256, 2048)])
+def test_gemm_split_k_is_correct_and_deterministic(env, epi, M, N, K):
+    """gemm_waves = 13: two workgroups per 256x256 tile, each half of K, partial accumulators exchanged through a workspace
+    and added in a fixed order -- same bits on every run, and the usual accuracy against fp32"""
+    torch, L, ffi = env
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    gate = torch.randn(N, device="cuda", generator=g)
+    c0 = torch.randn(M, N, device="cuda", generator=g)
+    lin = a.float() @ w.float().t() + bias
+    if epi == 3:
+        init, want = c0, c0 + gate * lin
+    elif epi == 6:
+        init = c0.to(torch.bfloat16)
+        want = init.float() + gate * lin
+    else:
+        init, want = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16), lin
+    outs = []
+    try:
+        ffi.check(L.r3g_set_option(b"gemm_waves", 13))
+        for _ in range(3):
+            c = init.clone()
+            ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                                    gate.data_ptr() if epi in (3, 6) else None, M, N, K, epi, 1, stream(torch)))
+            outs.append(c)
+    finally:
+        ffi.check(L.r3g_set_option(b"gemm_waves", 0))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_l2(outs[0].float(), want) <= 5e-3
+
+
 def test_gemm_strided_views(env):
     """column slab of a wider weight (ldw > K) and of wider activations / outputs (lda, ldc > width)"""
     torch, L, ffi = env

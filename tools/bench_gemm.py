@@ -30,6 +30,8 @@ SHAPES = {
     # the geo decoder's residual GEMMs with the 16-bit residual stream
     "geo16": [(131072, 1024, 1024, 6), (131072, 1024, 4096, 6), (131072, 1024, 1024, 3), (131072, 1024, 4096, 3)],
     # K sweep at the geo decoder's M: intercept = fixed cost per tile round (prologue + epilogue), slope = cost per k
+    # the DiT's under-filled deep-K residual GEMMs (120 tiles of 256x256): split-K candidates
+    "split": [(7552, 1024, 5120, 3), (7552, 1024, 4096, 3), (7552, 1024, 2048, 3), (7552, 1024, 1024, 3)],
     "ksweep": [(131072, 1024, k, e) for e in (0, 3) for k in (128, 256, 512, 1024, 2048)],
     # ragged edges for the screen
     "edge": [(300, 256, 128, 0), (77, 512, 256, 3), (1371, 1024, 1024, 1), (515, 768, 1024, 3), (4442, 1024, 1536, 4),
