@@ -561,6 +561,52 @@ hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln
     return hipGetLastError();
 }
 
+// bf16 [rows][K] -> fp8 e4m3 (OCP) [rows][K] with one fp32 scale per row: q = round(x / scale), scale = amax / 448.
+// One wave per row, 8 elements per lane and step (K % 8 == 0): one pass for the maximum, one for the conversion (the row
+// stays in L2 between them).  v_cvt_pk_fp8_f32 saturates and rounds to nearest even.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const uint16_t* __restrict__ x, int64_t ldx, int rows, int K,
+                                                             uint8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    float amax = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            amax = fmaxf(amax, fabsf(__uint_as_float(w[k] << 16)));
+            amax = fmaxf(amax, fabsf(__uint_as_float(w[k] & 0xFFFF0000u)));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    uint8_t* qr = q + (int64_t)row * ldq;
+    for (int c = lane * 8; c < K; c += 512) {
+        const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[0] << 16) * inv, __uint_as_float(w[0] & 0xFFFF0000u) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[1] << 16) * inv, __uint_as_float(w[1] & 0xFFFF0000u) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[2] << 16) * inv, __uint_as_float(w[2] & 0xFFFF0000u) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[3] << 16) * inv, __uint_as_float(w[3] & 0xFFFF0000u) * inv, hi, true);
+        *reinterpret_cast<uint2*>(qr + c) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
+
+hipError_t quant_fp8_rows_launch(const uint16_t* x, int64_t ldx, int rows, int K, uint8_t* q, int64_t ldq, float* scale,
+                                 hipStream_t s) {
+    if (K % 8 || (ldx & 7) || (ldq & 7) || rows < 0) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, K, q, ldq, scale);
+    return hipGetLastError();
+}
+
 hipError_t im2col_launch(const float* img, int S, int ps, uint16_t* out, int Kpad, hipStream_t s) {
     const int P = S / ps;
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);

@@ -1029,6 +1029,260 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb, fl
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// FP8 (OCP e4m3) form of the phased kernel, for BASELINE.json's configs[3] ("config 4"): the same 128-byte LDS rows, LDS-DMA
+// staging, phases and hazards -- a k-tile is 128 fp8 instead of 64 bf16, so GemmArgs describes the operands as matrices
+// of byte PAIRS (K / 2 columns of 16 bits) and nothing in the staging changes.  A fragment is the 32 bytes of k-block
+// (lane >> 4) of a row; v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate) has the C/D layout of the 16x16x32
+// bf16 form, so the epilogues are shared.  Operands carry one fp32 scale per row (quantised by quant_fp8_rows_kernel in
+// elem.hip); the hardware block scales are set to 1.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8f_kernel(GemmArgs pa, GemmArgs pb, const float* __restrict__ scale_a,
+                                                     const float* __restrict__ scale_w) {
+    constexpr bool SPLIT = false;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, MI = 8;
+    constexpr int HALF = 16384, BUF = 4 * HALF;   // buffer: [A_0][A_1][W_0][W_1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // split: consecutive workgroups (same XCD, same L2) are the two halves of one tile
+    const int wg_all = wg_lin;
+    const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
+    const bool second = wg_all >= tiles_a;
+    typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kSecond = (sizeof(GemmArgs) + alignof(GemmArgs) - 1) / alignof(GemmArgs) * alignof(GemmArgs);
+    const GemmArgs& p = *(const GemmArgs*)(const GemmArgs __attribute__((address_space(4)))*)(ka + (second ? kSecond : 0));
+    (void)pb;
+    const int wg = second ? wg_all - tiles_a : wg_all;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int rg = p.raster_group < 0 ? 4 : p.raster_group;
+    const int GN = rg > 0 ? rg : tiles_n;
+    const int rows_all = tiles_m * p.batch;
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // ---- staging sources: this lane's 16-byte chunk of piece (wid*2 + i) of each half-tile, at k = 0, as 32-bit element
+    // offsets from the (wave-uniform) operand bases: the scaled MFMA is not tied to its accumulator registers, so this
+    // kernel has no room for eight 64-bit pointers (spilled pointers cost a vmcnt(0) before every LDS-DMA)
+    uint32_t offSA[2][2], offSW[2][2];
+    const uint16_t* const baseA = p.A + (int64_t)batch * p.strideA;
+    const uint16_t* const baseW = p.W;
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wid * 2 + i) * 8 + (lane >> 3);        // row inside the half-tile
+            const int kc = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int ga = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+                int gw = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+                ga = ga < p.M ? ga : p.M - 1;
+                gw = gw < p.N ? gw : p.N - 1;
+                offSA[h][i] = (uint32_t)((int64_t)ga * p.lda + kc * 8);
+                offSW[h][i] = (uint32_t)((int64_t)gw * p.ldw + kc * 8);
+            }
+        }
+    }
+    char* const dst0 = smem + wid * 2048;   // + buffer * BUF + region * HALF + i * 1024
+    auto stage_a = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + (int64_t)t * BK + offSA[h][i]),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + h * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+    auto stage_w = [&](int h, int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseW + (int64_t)t * BK + offSW[h][i]),
+                                             (__attribute__((address_space(3))) void*)(dst0 + buf * BUF + (2 + h) * HALF + i * 1024),
+                                             16, 0, 0);
+    };
+
+    // ---- fragment read addresses (bytes inside a half-tile) for the two 32-wide k-steps
+    const int sw = (lane >> 1) & 7;   // == ((row >> 1) & 7): the sub-tile / wave offsets are multiples of 16 rows
+    int offA[2], offW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        offA[kk] = (wr * 64 + (lane & 15)) * 128 + ((((lane >> 4) * 2 + kk) ^ sw) << 4);
+        offW[kk] = (wc * 32 + (lane & 15)) * 128 + ((((lane >> 4) * 2 + kk) ^ sw) << 4);
+    }
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int unit_scale = 0x7F7F7F7F;   // e8m0 127 = 2^0 in every byte
+    i32x8 af[4], wf0[2], wf1[2];   // A sub-tile (shared by both m-halves), W_0 and W_1 sub-tiles: 32 fp8 per lane each
+
+    auto frag = [&](const char* base) -> i32x8 {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(base + 0), hi = *reinterpret_cast<const i32x4*>(base + 0);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    (void)frag;
+    auto frag2 = [&](const char* p0, const char* p1) -> i32x8 {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(p0), hi = *reinterpret_cast<const i32x4*>(p1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_a = [&](int h, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* base = smem + buf * BUF + h * HALF + i * 2048;
+            af[i] = frag2(base + offA[0], base + offA[1]);
+        }
+    };
+    auto read_w0 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* base = smem + buf * BUF + 2 * HALF + j * 2048;
+            wf0[j] = frag2(base + offW[0], base + offW[1]);
+        }
+    };
+    auto read_w1 = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* base = smem + buf * BUF + 3 * HALF + j * 2048;
+            wf1[j] = frag2(base + offW[0], base + offW[1]);
+        }
+    };
+    // one accumulator quadrant x K = 128 fp8: 8 block-scaled MFMAs (16x16x128), unit scales (the row scales are applied
+    // to the accumulators before the epilogue)
+    auto mma = [&](auto HA, auto HW) {
+        constexpr int ha = decltype(HA)::value, hw = decltype(HW)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                // inline asm ties the destination to the accumulator: the builtin leaves them untied, hipcc then rotates the
+                // 128 accumulator registers through fresh ones and spills the staging addresses (a vmcnt(0) per LDS-DMA)
+                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                             : "+v"(acc[hw * 2 + j][ha * 4 + i])
+                             : "v"(hw ? wf1[j] : wf0[j]), "v"(af[i]), "v"(unit_scale));
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    const int nk = (SPLIT ? p.K / 2 : p.K) / BK;   // even, >= 2 (checked by the launcher)
+    stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+    stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    R3G_BAR();
+    if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
+
+    // four phases on the k-tile in buffer `b`; FULL: not the last iteration (every staging slot has a tile to load)
+    auto four_phases = [&](auto B, auto FULL, const int t) {
+        constexpr int b = decltype(B)::value;
+        constexpr bool full = decltype(FULL)::value;
+        // tiles staged by these phases: b == 0: A_1(t+1)->1, then W_0, A_0, W_1 of t+2 -> 0
+        //                               b == 1: A_1(t+1)->0, then W_0, A_0, W_1 of t+2 -> 1   (t = the k-tile read here)
+        // phase 1
+        read_w0(b);
+        R3G_SB();
+        read_a(0, b);
+        R3G_SB();
+        if (full || b == 0) stage_a(1, t + 1, b ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // W_0's four reads have returned: it is restaged next phase
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 2
+        read_w1(b);
+        R3G_SB();
+        if (full) stage_w(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I0{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 3
+        read_a(1, b);
+        R3G_SB();
+        if (full) stage_a(0, t + 2, b);
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I1{});
+        R3G_SB();
+        R3G_BAR();
+        // phase 4
+        if (full) {
+            stage_w(1, t + 2, b);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (b == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last iteration: A_1 of the last k-tile
+        }
+        R3G_BAR();
+        R3G_SB();
+        mma(I1{}, I0{});
+        R3G_SB();
+        R3G_BAR();
+    };
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {
+        four_phases(I0{}, std::true_type{}, t);
+        four_phases(I1{}, std::true_type{}, t + 1);
+    }
+    four_phases(I0{}, std::false_type{}, t);
+    four_phases(I1{}, std::false_type{}, t + 1);
+    if (wr == 0) R3G_BAR();
+
+    // fp8 operands carry one fp32 scale per row of A and per row of W: C = (sa[m] sw[n]) * sum_k a8 w8
+    {
+        f32x4 swv[4];
+        float sav[MI];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + ((lane >> 4) << 2);
+            swv[j] = *reinterpret_cast<const f32x4*>(scale_w + (n < p.N ? n : p.N - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            sav[i] = scale_a[(int64_t)batch * p.M + (m < p.M ? m : p.M - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] *= swv[j] * sav[i];
+    }
+    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
+}
+
+
+template <int EPI>
+hipError_t launch_gemm8_fp8(const GemmArgs& p, const float* scale_a, const float* scale_w, hipStream_t s) {
+    const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
+    const size_t lds = 131072;
+    auto k = gemm8f_kernel<EPI>;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    GemmArgs none{};
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p, none, scale_a, scale_w);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Persistent form of the phased kernel: the grid is one workgroup per CU (balanced over the dispatch rounds) and every
 // workgroup walks tiles w, w + G, w + 2G, ...  Between two tiles it issues the LDS-DMA of the NEXT tile's first k-tile,
 // runs the epilogue of the tile it just finished out of a separate 32 KiB of LDS scratch (4 KiB per wave, 32 rows per
@@ -1499,5 +1753,25 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
 }
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) { return gemm_launch2(p, batch, nullptr, 0, s); }
+
+// FP8 operands: A8 [M][K] and W8 [N][K] bytes (e4m3), one fp32 scale per row of each.  K % 256 == 0, lda / ldw in bytes.
+hipError_t gemm_fp8_launch(const GemmArgs& p_in, const float* scale_a, const float* scale_w, hipStream_t s) {
+    GemmArgs p = p_in;
+    if (p.K % 256 || p.K < 256 || (p.lda & 15) || (p.ldw & 15) || (p.N & 3) || !scale_a || !scale_w) return hipErrorInvalidValue;
+    if ((int64_t)p.M * p.lda >= (1ll << 32) || (int64_t)p.N * p.ldw >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit staging offsets
+    p.batch = 1;
+    p.K /= 2; p.lda /= 2; p.ldw /= 2;          // the kernel sees byte pairs (file comment of gemm8f_kernel)
+    p.raster_group = g_gemm_raster;
+    p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;
+    ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * (2.0 * p.K), s);
+    switch (p.epi) {
+        case EPI_BF16: return launch_gemm8_fp8<EPI_BF16>(p, scale_a, scale_w, s);
+        case EPI_BF16_GELU_TANH: return launch_gemm8_fp8<EPI_BF16_GELU_TANH>(p, scale_a, scale_w, s);
+        case EPI_BF16_GELU_ERF: return launch_gemm8_fp8<EPI_BF16_GELU_ERF>(p, scale_a, scale_w, s);
+        case EPI_RESID_F32: return launch_gemm8_fp8<EPI_RESID_F32>(p, scale_a, scale_w, s);
+        case EPI_RESID_BF16: return launch_gemm8_fp8<EPI_RESID_BF16>(p, scale_a, scale_w, s);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 }  // namespace r3g

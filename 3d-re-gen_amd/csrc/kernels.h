@@ -177,6 +177,10 @@ hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln
 hipError_t im2col_launch(const float* img, int S, int ps, uint16_t* out, int Kpad, hipStream_t s);
 // x(f32)[r][c] = a(f32)[r][c] (+ pos[r][c]) ; assorted small helpers
 hipError_t add_rows_launch(float* x, int64_t ldx, const float* pos, int64_t ldp, int rows, int C, hipStream_t s);
+// FP8 (OCP e4m3) path, BASELINE.json configs[3]: row-scaled quantisation and the fp8 form of the phased GEMM
+hipError_t quant_fp8_rows_launch(const uint16_t* x, int64_t ldx, int rows, int K, uint8_t* q, int64_t ldq, float* scale,
+                                 hipStream_t s);
+hipError_t gemm_fp8_launch(const GemmArgs& p, const float* scale_a, const float* scale_w, hipStream_t s);
 hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStream_t s);
 
 }  // namespace r3g

@@ -911,6 +911,26 @@ int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t l
     return R3G_OK;
 }
 
+int r3g_op_quant_fp8(const uint16_t* d_x, int64_t ldx, int rows, int k_, uint8_t* d_q, int64_t ldq, float* d_scale, void* stream) {
+    if (!d_x || !d_q || !d_scale) return fail(R3G_ERR_INVALID, "r3g_op_quant_fp8: null argument");
+    hipError_t e = quant_fp8_rows_launch(d_x, ldx, rows, k_, d_q, ldq, d_scale, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "r3g_op_quant_fp8");
+    return R3G_OK;
+}
+
+int r3g_op_gemm_fp8(const uint8_t* d_a8, int64_t lda, const float* d_scale_a, const uint8_t* d_w8, int64_t ldw,
+                    const float* d_scale_w, const float* d_bias, void* d_c, int64_t ldc, const float* d_gate, int m_, int n_,
+                    int k_, int epilogue, void* stream) {
+    if (!d_a8 || !d_w8 || !d_scale_a || !d_scale_w || !d_c) return fail(R3G_ERR_INVALID, "r3g_op_gemm_fp8: null argument");
+    GemmArgs p{};
+    p.A = reinterpret_cast<const uint16_t*>(d_a8); p.lda = lda; p.W = reinterpret_cast<const uint16_t*>(d_w8); p.ldw = ldw;
+    p.bias = d_bias; p.C = d_c; p.ldc = ldc; p.gate = d_gate;
+    p.M = m_; p.N = n_; p.K = k_; p.epi = epilogue;
+    hipError_t e = gemm_fp8_launch(p, d_scale_a, d_scale_w, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "r3g_op_gemm_fp8 (needs K % 256 == 0, 16-byte aligned rows, N % 4 == 0, a bf16 / residual epilogue)");
+    return R3G_OK;
+}
+
 int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
                      int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream) {
     AttnArgs p{};

@@ -57,6 +57,8 @@ SYMBOLS = {
     "r3g_vae_decode": (_I, [_P, _P, _P, _P]),
     "r3g_grid_query": (_I, [_P, _D, _I, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
+    "r3g_op_quant_fp8": (_I, [_P, ctypes.c_int64, _I, _I, _P, ctypes.c_int64, _P, _P]),
+    "r3g_op_gemm_fp8": (_I, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _P]),
     "r3g_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "r3g_set_staging": (_I, [_I]),
     "r3g_set_option": (_I, [ctypes.c_char_p, _I]),

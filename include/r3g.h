@@ -225,6 +225,15 @@ int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t l
  * the two middle 4-key blocks are swapped (key 8g+4h+e at position 8h+4g+e; python: r3g.layout.make_vt). */
 int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d_vt, uint16_t* d_o, int batch, int heads,
                      int lq, int lq_pad, int lk, int lk_pad, int shared_kv, int use_lds_dma, void* stream);
+/* FP8 operands (BASELINE.json configs[3]).  quant_fp8: bf16 [rows][k] -> OCP e4m3 bytes [rows][k] + one fp32 scale per row
+ * (amax / 448; round to nearest even, saturating).  gemm_fp8: C = epilogue((scale_a[m] scale_w[n]) sum_k a8[m][k] w8[n][k] +
+ * bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 matrix rate); k % 256 == 0, lda / ldw in bytes and multiples
+ * of 16, epilogue one of 0, 1, 2 (bf16 out), 3 (fp32 residual), 6 (bf16 residual).  Test / benchmark hooks: the model path
+ * does not use them yet. */
+int r3g_op_quant_fp8(const uint16_t* d_x, int64_t ldx, int rows, int k, uint8_t* d_q, int64_t ldq, float* d_scale, void* stream);
+int r3g_op_gemm_fp8(const uint8_t* d_a8, int64_t lda, const float* d_scale_a, const uint8_t* d_w8, int64_t ldw,
+                    const float* d_scale_w, const float* d_bias, void* d_c, int64_t ldc, const float* d_gate, int m, int n,
+                    int k, int epilogue, void* stream);
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).  Families, in order:
  * 0 gemm, 1 attention, 2 layernorm, 3 qkv_split, 4 gemv, 5 elementwise, 6 mc_classify, 7 mc_other, 8 mesh
  * cleaners (n >= 9).  work = algorithmic FLOPs (0,1,4) / bytes (6,8) summed over the launches since r3g_prof_enable(1). */
