@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
     const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
     uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
+    const bool to_fp8 = p.y8 != nullptr;      // wave-uniform
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (i < nv) {
@@ -92,11 +94,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 const float4 a = *reinterpret_cast<const float4*>(sh + c);
                 o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
             }
+            if (to_fp8) {   // keep the finished values (the row's maximum decides their scale), write below
+                v[i] = make_float4(o[0], o[1], o[2], o[3]);
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                continue;
+            }
             uint2 pk;
             pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
             pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
             *reinterpret_cast<uint2*>(y + c) = pk;
         }
+    if (to_fp8) {
+        // e4m3 operand of an fp8 GEMM: q = round(o / scale), scale = amax / 448 (one per row: the row is all here)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+        const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / sc;
+        if (lane == 0) p.y_scale[row] = sc;
+        uint8_t* y8 = p.y8 + (int64_t)row * p.ldy8;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_V4; ++i)
+            if (i < nv) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w, true);
+                *reinterpret_cast<uint32_t*>(y8 + (i * 64 + lane) * 4) = (uint32_t)w;
+            }
+    }
 }
 
 // generic-C variant (C % 64 == 0, C <= 2048): scalar per-lane elements (tiny configs, C = 64 / 128)
@@ -463,6 +487,7 @@ hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;
     if (p.C % 64 || p.C > 2048) return hipErrorInvalidValue;
     ProfScope ps(PC_LAYERNORM, 6.0 * (double)p.rows * p.C, s);
+    if (p.y8 && (p.C % 256 || (p.ldy8 & 3) || !p.y_scale)) return hipErrorInvalidValue;
     if (p.x_bf16) {
         if (p.C % 256 || (p.ldx & 3) || (p.ldy & 3) || (p.x_batch_stride & 3)) return hipErrorInvalidValue;
         hipLaunchKernelGGL(layernorm_kernel<true>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);

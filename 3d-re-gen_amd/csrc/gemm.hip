@@ -297,6 +297,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     const int mrow = m0 + wr * WROWS + (lane & 15);
     const int ncol = n0 + wc * 64 + ((lane >> 4) << 2);
     const float* gate = p.gate ? p.gate + (int64_t)batch * p.strideGate : nullptr;
+    if constexpr (EPI == EPI_FP8_GELU_ERF) {
+        // e4m3 output with a static scale: the operand of the fp8 GEMM that follows (the MLP hidden of the geo decoder)
+        uint8_t* C8 = reinterpret_cast<uint8_t*>(p.C) + (int64_t)batch * p.strideC;
+        const float inv = p.out_inv_scale;
+        const bool wide = lds_wave != nullptr && PI == MI && (p.N & 15) == 0 && (p.ldc & 15) == 0 && (p.strideC & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol + j * 16;
+            f32x4 bj = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bj = *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : p.N - 4));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const f32x4 v = acc[j][i] + bj;
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_erf(v[0]) * inv, gelu_erf(v[1]) * inv, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_erf(v[2]) * inv, gelu_erf(v[3]) * inv, w, true);
+                const int r = i * 16 + (lane & 15), m = mrow + i * 16;
+                if (wide) *reinterpret_cast<uint32_t*>(lds_wave + r * 64 + ((j ^ (r & 3)) << 4) + ((lane >> 4) << 2)) = (uint32_t)w;
+                else if (n < p.N && m < p.M) *reinterpret_cast<uint32_t*>(C8 + (int64_t)m * p.ldc + n) = (uint32_t)w;
+            }
+        }
+        if (wide) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cc = lane & 3, n = n0 + wc * 64 + cc * 16;
+#pragma unroll
+            for (int t = 0; t < WROWS / 16; ++t) {       // 16 rows x 64 contiguous bytes per store instruction
+                const int rr = t * 16 + (lane >> 2);
+                const int m = m0 + wr * WROWS + rr;
+                const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 64 + ((cc ^ (rr & 3)) << 4));
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C8 + (int64_t)m * p.ldc + n) = d;
+            }
+        }
+        return;
+    }
     if constexpr (EPI == EPI_RESID_BF16) {
         // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
         uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
@@ -1735,7 +1771,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     // algorithmic bytes of a launch: each operand read once, the result written once (fp32 residual: read + written)
     auto alg_bytes = [](const GemmArgs& g) {
         if (g.M <= 0) return 0.0;
-        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 ? 4.0 : 2.0);
+        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 ? 4.0 : (g.epi == EPI_FP8_GELU_ERF ? 1.0 : 2.0));
         return (double)g.batch * (2.0 * g.M * g.K + out * (double)g.M * g.N) + 2.0 * (double)g.N * g.K;
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
@@ -1770,6 +1806,8 @@ hipError_t gemm_fp8_launch(const GemmArgs& p_in, const float* scale_a, const flo
         case EPI_BF16_GELU_ERF: return launch_gemm8_fp8<EPI_BF16_GELU_ERF>(p, scale_a, scale_w, s);
         case EPI_RESID_F32: return launch_gemm8_fp8<EPI_RESID_F32>(p, scale_a, scale_w, s);
         case EPI_RESID_BF16: return launch_gemm8_fp8<EPI_RESID_BF16>(p, scale_a, scale_w, s);
+        case EPI_QKV: return launch_gemm8_fp8<EPI_QKV>(p, scale_a, scale_w, s);
+        case EPI_FP8_GELU_ERF: return launch_gemm8_fp8<EPI_FP8_GELU_ERF>(p, scale_a, scale_w, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -15,6 +15,7 @@ enum GemmEpilogue {
     EPI_F32 = 4,             // C(f32) = acc + bias
     EPI_QKV = 5,             // split into attention operands: per-head q/k norm, Q/K [B][H][L][64], V^T [B][H][64][L]
     EPI_RESID_BF16 = 6,      // C(bf16) = bf16(C + gate[b][n] * (acc + bias)): a 16-bit residual stream (sum formed in fp32)
+    EPI_FP8_GELU_ERF = 7,    // C(e4m3) = fp8(gelu_erf(acc + bias) * out_inv_scale): operand of a following fp8 GEMM (static scale)
 };
 
 enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
@@ -62,6 +63,7 @@ struct GemmArgs {
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
     int batch;          // filled in by gemm_launch
+    float out_inv_scale;   // EPI_FP8_GELU_ERF: 1 / (the static scale of the fp8 output)
     int wide_epilogue;  // 1: stores go through the wave-private LDS transpose (row-contiguous 16-byte accesses)
     int raster_group;   // tile columns per rasterisation group (0 = row-major), filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
@@ -118,6 +120,7 @@ struct LnArgs {
     const float* x; int64_t ldx;        // f32 [rows][C] (bf16 [rows][C] behind the same pointer when x_bf16 != 0)
     int x_bf16;
     uint16_t* y; int64_t ldy;           // bf16 [rows][C]
+    uint8_t* y8; int64_t ldy8; float* y_scale;   // y8 != null: e4m3 [rows][C] + one scale per row INSTEAD of y (C % 256 == 0)
     int64_t x_batch_stride, y_batch_stride;  // row r lives at batch (r / rows_per_batch), local row r % rows_per_batch
     const float* w; const float* b;     // affine [C] or null
     const float* scale; const float* shift; int64_t mod_stride;  // per-batch [C] or null

@@ -49,6 +49,8 @@ static bool g_overlap_mlp = true;     // single blocks: MLP-in GEMM on a second 
 static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
+static bool g_geo_fp8 = false;   // BASELINE.json configs[3]: the geo decoder's c_q / MLP GEMMs on fp8 (e4m3) operands; off by default
+constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP hidden: |GELU| up to 28 representable
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
 
@@ -83,6 +85,11 @@ struct Model {
     // second stream: the MLP half of a single block's linear1 runs beside the attention kernel (see dit_forward_cfg_dedup)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // fp8 mode of the geo decoder (option geo_fp8): e4m3 copies of its weights with one scale per output row, made on
+    // first use; per-row scales of the activations LayerNorm quantises; the constant scale vector of the MLP hidden
+    struct W8 { uint8_t* w8; float* sw; };
+    std::unordered_map<const void*, W8> w8;
+    float *fp8_sa = nullptr, *fp8_sconst = nullptr;
     std::string err;
 
     const Tensor* find(const std::string& name) const {
@@ -613,6 +620,61 @@ static int vae_decode(Model& m, const float* latents, hipStream_t s) {
     return R3G_OK;
 }
 
+// ---- fp8 mode helpers ------------------------------------------------------------------------------------------
+static int fill_f32(float* dst, int n, float v, hipStream_t s) {
+    std::vector<float> h((size_t)n, v);
+    R3G_TRY(hipMemcpyAsync(dst, h.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    R3G_TRY(hipStreamSynchronize(s));
+    return R3G_OK;
+}
+
+static int lin_fp8(Model& m, const Lin& l, Model::W8* out, hipStream_t s) {
+    auto it = m.w8.find(l.w);
+    if (it == m.w8.end()) {
+        Model::W8 q{};
+        R3G_TRY(hipMalloc((void**)&q.w8, (size_t)l.N * l.K));
+        R3G_TRY(hipMalloc((void**)&q.sw, 4 * (size_t)rup(l.N, 64)));
+        R3G_TRY(quant_fp8_rows_launch(l.w, l.ldw, l.N, l.K, q.w8, l.K, q.sw, s));
+        it = m.w8.emplace(l.w, q).first;
+    }
+    *out = it->second;
+    return R3G_OK;
+}
+
+// C = epi(A8 W8^T): A8 [M][K] e4m3 with row scales sa, weights quantised on first use
+static int gemm_fp8(Model& m, const uint8_t* A8, const float* sa, const Lin& l, void* C, int64_t ldc, int M, int epi,
+                    const QkvSplitArgs* q, int qkv_layout, hipStream_t s) {
+    Model::W8 w;
+    R3G_RC(lin_fp8(m, l, &w, s));
+    GemmArgs p{};
+    p.A = reinterpret_cast<const uint16_t*>(A8); p.lda = l.K;
+    p.W = reinterpret_cast<const uint16_t*>(w.w8); p.ldw = l.K;
+    p.bias = l.b; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = l.N; p.K = l.K; p.epi = epi;
+    p.out_inv_scale = 1.0f / kGeoHiddenScale;
+    if (q) {
+        p.qkv.Q = q->Q; p.qkv.K = q->K; p.qkv.Vt = q->Vt; p.qkv.Lq_pad = q->Lq_pad; p.qkv.Lk_pad = q->Lk_pad;
+        p.qkv.dst_row0 = q->dst_row0; p.qkv.heads = q->H; p.qkv.layout = qkv_layout; p.qkv.norm = q->norm;
+        p.qkv.qw = q->qw; p.qkv.qb = q->qb; p.qkv.kw = q->kw; p.qkv.kb = q->kb; p.qkv.eps = q->eps;
+        p.qkv.q_scale = q->q_scale;
+    }
+    hipError_t e = gemm_fp8_launch(p, sa, w.sw, s);
+    if (e != hipSuccess) return hip_fail(e, "gemm_fp8_launch");
+    return R3G_OK;
+}
+
+static int layernorm_fp8(const float* x, int64_t ldx, uint8_t* y8, int64_t ldy8, float* scale, int rows, int C, const float* w,
+                         const float* b, float eps, hipStream_t s, int x_bf16) {
+    LnArgs p{};
+    p.x = x; p.ldx = ldx; p.x_bf16 = x_bf16;
+    p.y8 = y8; p.ldy8 = ldy8; p.y_scale = scale;
+    p.w = w; p.b = b;
+    p.rows = rows; p.C = C; p.rows_per_batch = rows; p.eps = eps;
+    hipError_t e = layernorm_launch(p, s);
+    if (e != hipSuccess) return hip_fail(e, "layernorm_launch(fp8)");
+    return R3G_OK;
+}
+
 static int grid_query(Model& m, double bound, int R, float* grid, int64_t start, int64_t count, hipStream_t s) {
     const r3g_model_config& c = m.c;
     if (!m.have_z) return fail(R3G_ERR_STATE, "r3g_grid_query: r3g_vae_decode has not run");
@@ -649,8 +711,19 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         // read / written 7 times per point, 0.9 TB per object in fp32.  The bf16 stream lives in the same buffer (m.f32a).
         const int xb = g_geo_resid_bf16 && W % 256 == 0 ? 1 : 0;
         const int epi_x0 = xb ? EPI_BF16 : EPI_F32, epi_res = xb ? EPI_RESID_BF16 : EPI_RESID_F32;
+        // fp8 mode (option geo_fp8, BASELINE.json configs[3]): LayerNorm writes e4m3 + row scales, c_q / c_fc / mlp.c_proj run
+        // on fp8 operands; the attention, its output projection and the residual stream stay bf16
+        const bool f8 = g_geo_fp8 && xb && W % 256 == 0 && lfc.N % 256 == 0;
+        uint8_t* xn8 = reinterpret_cast<uint8_t*>(m.xn);
+        uint8_t* hid8 = reinterpret_cast<uint8_t*>(m.hid);
+        if (f8 && !m.fp8_sa) {
+            R3G_TRY(hipMalloc((void**)&m.fp8_sa, 4 * (size_t)m.qc));
+            R3G_TRY(hipMalloc((void**)&m.fp8_sconst, 4 * (size_t)m.qc));
+            R3G_RC(fill_f32(m.fp8_sconst, m.qc, kGeoHiddenScale, s));
+        }
         R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, epi_x0, nullptr, 0, 1, s));
-        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
+        if (f8) R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l1w, l1b, 1e-6f, s, xb));
+        else R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
         q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
@@ -661,12 +734,19 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
         }
-        R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
+        if (f8) R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lcq, nullptr, 0, n, EPI_QKV, &q, QKV_Q_ONLY, s));
+        else R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
         R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
         R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0, 1, s));
-        R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
-        R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
-        R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, epi_res, nullptr, 0, 1, s));
+        if (f8) {
+            R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l3w, l3b, 1e-6f, s, xb));
+            R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lfc, hid8, lfc.N, n, EPI_FP8_GELU_ERF, nullptr, 0, s));
+            R3G_RC(gemm_fp8(m, hid8, m.fp8_sconst, lfp, m.f32a, W, n, epi_res, nullptr, 0, s));
+        } else {
+            R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
+            R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+            R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, epi_res, nullptr, 0, 1, s));
+        }
         R3G_TRY(ln_dot_launch(m.f32a, W, n, W, c.vae_ln_post, lpw, lpb, 1e-5f, ow, ob, grid + start + off, s, xb));
     }
     return R3G_OK;
@@ -730,6 +810,12 @@ static void model_free(Model* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->aux) (void)hipStreamDestroy(m->aux);
+    for (auto& kv : m->w8) {
+        (void)hipFree(kv.second.w8);
+        (void)hipFree(kv.second.sw);
+    }
+    if (m->fp8_sa) (void)hipFree(m->fp8_sa);
+    if (m->fp8_sconst) (void)hipFree(m->fp8_sconst);
     delete m;
 }
 
@@ -969,6 +1055,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
+    else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value != 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);

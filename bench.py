@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--octree-resolution", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fp8-geo", action="store_true",
+                    help="BASELINE.json configs[3] direction: the geo decoder's c_q / MLP GEMMs on fp8 (e4m3) operands; NOT the "
+                         "headline configuration (the line says so in dtype / config)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,6 +181,8 @@ def main():
     from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
     from r3g import ffi
     pipe = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("synthetic:%s:0" % a.model, device="cuda:%d" % local)
+    if a.fp8_geo:
+        ffi.check(ffi.lib().r3g_set_option(b"geo_fp8", 1))
     cfg = pipe.cfg
     S, R = a.inference_steps, a.octree_resolution
     n_local = a.warmup + a.steps + 1
@@ -254,7 +259,7 @@ def main():
         out = {"metric": "objects/sec (50-step Hunyuan3D-2 DiT + 256^3 marching cubes)", "value": total / dt,
                "unit": "objects/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "synthetic",
+               "dtype": "bf16+fp8(e4m3 operands in the geo decoder GEMMs)" if a.fp8_geo else "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: %d synthetic 512x512 RGBA crops per GPU, Hunyuan3D-2 %s dims bf16, "
                                       "%d flow-matching steps x CFG 2, %d^3 grid query + Lewiner marching cubes"
                                       % (a.steps, a.model, S, R + 1),

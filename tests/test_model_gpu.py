@@ -293,6 +293,38 @@ def test_full_width_conditioner_vae_and_grid_points(wide):
     assert d <= TOL["grid_logits"]
 
 
+def test_geo_decoder_fp8_mode(wide):
+    """option geo_fp8 (BASELINE.json configs[3]): the geo decoder's c_q / MLP GEMMs on e4m3 operands (LayerNorm quantises with
+    row scales, the MLP hidden with a static scale) -- grid logits against the fp32 oracle, and against the bf16 path"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(3072, 64, generator=g)
+    with torch.no_grad():
+        z_ref = wide.oracle.vae(lat[None] / wide.oracle.vae.scale_factor)
+    wide.gpu.vae_decode(lat, return_z=True)
+    R, start, count = 256, 257 * 257 * 100 + 12345, 3000
+    pts = torch.from_numpy(wide.H.dense_grid_points(1.01, R)[start:start + count])
+    with torch.no_grad():
+        ref = wide.oracle.vae.geo_decoder(queries=pts[None], latents=z_ref)[0, :, 0]
+    out = torch.zeros(257 ** 3, device="cuda")
+    wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+    bf16 = out[start:start + count].cpu().clone()
+    try:
+        ffi.check(L.r3g_set_option(b"geo_fp8", 1))
+        out.zero_()
+        wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+    finally:
+        ffi.check(L.r3g_set_option(b"geo_fp8", 0))
+    fp8 = out[start:start + count].cpu()
+    d = (fp8 - ref).abs().max().item() / ref.abs().max().item()
+    report("full-width grid logits, geo decoder in fp8 mode (257^3 slice)", d, TOL["grid_logits_fp8"])
+    report("  fp8 mode against the bf16 path", (fp8 - bf16).abs().max().item() / bf16.abs().max().item(), TOL["grid_logits_fp8"])
+    assert torch.isfinite(fp8).all() and d <= TOL["grid_logits_fp8"]
+    assert not torch.equal(fp8, bf16)                      # the mode really took the other path
+
+
 def test_fused_and_unfused_paths_agree(tiny):
     """A/B switches: the QKV epilogue fusion and the batched modulation GEMV must reproduce the separate kernels."""
     import torch
