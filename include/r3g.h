@@ -228,8 +228,8 @@ int r3g_op_attention(const uint16_t* d_q, const uint16_t* d_k, const uint16_t* d
 /* FP8 operands (BASELINE.json configs[3]).  quant_fp8: bf16 [rows][k] -> OCP e4m3 bytes [rows][k] + one fp32 scale per row
  * (amax / 448; round to nearest even, saturating).  gemm_fp8: C = epilogue((scale_a[m] scale_w[n]) sum_k a8[m][k] w8[n][k] +
  * bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 matrix rate); k % 256 == 0, lda / ldw in bytes and multiples
- * of 16, epilogue one of 0, 1, 2 (bf16 out), 3 (fp32 residual), 6 (bf16 residual).  Test / benchmark hooks: the model path
- * does not use them yet. */
+ * of 16, epilogue one of 0, 1, 2 (bf16 out), 3 (fp32 residual), 6 (bf16 residual).  Test / benchmark hooks; the model uses
+ * the same kernels for the geo decoder under r3g_set_option("geo_fp8", 1). */
 int r3g_op_quant_fp8(const uint16_t* d_x, int64_t ldx, int rows, int k, uint8_t* d_q, int64_t ldq, float* d_scale, void* stream);
 int r3g_op_gemm_fp8(const uint8_t* d_a8, int64_t lda, const float* d_scale_a, const uint8_t* d_w8, int64_t ldw,
                     const float* d_scale_w, const float* d_bias, void* d_c, int64_t ldc, const float* d_gate, int m, int n,
@@ -252,7 +252,9 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * with more tiles than CUs), "gemm_num_cu" (CUs the tile rules assume, default 256), "attn_generation" (2 default |
  * 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_pipelined" (0), "attn_ablate"
  * (timing-only masks, results are garbage), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
- * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel).  None of them changes a
+ * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
+ * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q / MLP GEMMs on e4m3
+ * operands: a different precision, NOT result-preserving), "gemm_splitk" (0).  None of them changes a
  * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation
  * (different rounding points inside the softmax). */
 int r3g_set_option(const char* name, int value);
