@@ -1166,11 +1166,6 @@ __global__ __launch_bounds__(512) void gemm8f_kernel(GemmArgs pa, GemmArgs pb, c
     const int unit_scale = 0x7F7F7F7F;   // e8m0 127 = 2^0 in every byte
     i32x8 af[4], wf0[2], wf1[2];   // A sub-tile (shared by both m-halves), W_0 and W_1 sub-tiles: 32 fp8 per lane each
 
-    auto frag = [&](const char* base) -> i32x8 {
-        const i32x4 lo = *reinterpret_cast<const i32x4*>(base + 0), hi = *reinterpret_cast<const i32x4*>(base + 0);
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    (void)frag;
     auto frag2 = [&](const char* p0, const char* p1) -> i32x8 {
         const i32x4 lo = *reinterpret_cast<const i32x4*>(p0), hi = *reinterpret_cast<const i32x4*>(p1);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);

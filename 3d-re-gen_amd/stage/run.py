@@ -208,6 +208,10 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
     crops = rdist.broadcast_crops(crops, src=0)
     queue = rdist.WorkQueue(len(image_paths), name="r3g_stage_objects")
     shapegen, texgen, cleaners = factory(config, device)
+    # r3g_stream_outputs: every rank writes `<out>/<stem>/<stem>.glb` the moment the object is done (a consumer such as the
+    # scene-reconstruction stage can start per object) instead of returning the mesh to rank 0; the files
+    # are the same bytes either way (the writer is deterministic)
+    stream_out = bool(config.get("r3g_stream_outputs", False))
     mine, status = [], []
     while True:
         i = queue.claim()
@@ -218,7 +222,10 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
         try:
             image = Image.fromarray(crops[i].cpu().numpy(), "RGBA")
             mesh = generate_mesh(image, base, shapegen, texgen, cleaners, config)
-            mine.append((i, mesh))
+            if stream_out:
+                export_mesh(mesh, base, output_folder)
+            else:
+                mine.append((i, mesh))
             status.append((i, image_paths[i], "ok", time.time() - t0, rank))
         except Exception as e:      # one object failing must not fail the stage (reference :135-136 swallows it silently)
             print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))

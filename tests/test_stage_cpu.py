@@ -194,6 +194,21 @@ def test_gathered_meshes_are_byte_identical_to_the_one_rank_run(tmp_path, world)
     assert rep["objects"] == 7 and rep["ok"] == 7
 
 
+def test_streamed_outputs_equal_the_gathered_ones(tmp_path):
+    """r3g_stream_outputs: every rank writes its GLB as soon as the object is done; same bytes as the gather to rank 0"""
+    import yaml
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 5)
+    _run_ranks(tmp_path, cfg, 2, 29641, "content_factory")
+    gathered = _glbs(out)
+    conf = yaml.safe_load(open(cfg))
+    conf["r3g_stream_outputs"] = True
+    open(cfg, "w").write(yaml.safe_dump(conf))
+    r = _run_ranks(tmp_path, cfg, 2, 29642, "content_factory")
+    assert _glbs(out) == gathered and len(gathered) == 5
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["ok"] == 5 and sorted(set(rep["rank_of_object"])) == [0, 1]
+
+
 def test_failed_object_does_not_fail_the_distributed_stage(tmp_path):
     cfg, inp, out, names = make_distinct_scene(tmp_path, 4)
     r = _run_ranks(tmp_path, cfg, 2, 29631, "flaky_factory")
