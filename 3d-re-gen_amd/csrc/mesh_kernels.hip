@@ -191,13 +191,14 @@ __global__ void max_u32_kernel(const unsigned* __restrict__ v, int64_t n, unsign
     if ((threadIdx.x & 63) == 0 && m > *(volatile unsigned*)out) atomicMax(out, m);   // skip atomics that cannot win
 }
 
-// keep[f] = faces-of-component >= max(1, ceil(min_ratio * largest))
+// keep[f] = faces-of-component >= max(1, (unsigned)(min_ratio * largest)): MeshLab's small-component selection removes the
+// components with fewer faces than the TRUNCATED product (compute_selection_by_small_disconnected_components_per_face)
 __global__ void floater_flag_kernel(const int32_t* __restrict__ faces, int64_t nf, const int* __restrict__ root,
                                     const unsigned* __restrict__ cnt, const unsigned* __restrict__ largest,
                                     double min_ratio, unsigned* __restrict__ keep) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
-    const double t = ceil(min_ratio * (double)*largest);
+    const double t = floor(min_ratio * (double)*largest);
     const unsigned thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
     keep[i] = cnt[root[faces[3 * i]]] >= thr ? 1u : 0u;
 }

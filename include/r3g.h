@@ -79,7 +79,9 @@ int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xf
  * [*n_faces][3].  Each call compacts both arrays in place (survivors keep their order), stores the new sizes in
  * *n_verts / *n_faces and synchronises `stream`.
  *   remove_floaters  : drops every connected component (vertices joined by a face) with fewer faces than
- *                      max(1, ceil(min_ratio * faces of the largest component)), then unreferenced vertices.
+ *                      max(1, floor(min_ratio * faces of the largest component)) (MeshLab truncates the product), then
+ *                      unreferenced vertices.  Components are joined through shared VERTICES; MeshLab joins faces through
+ *                      shared edges, so two parts that touch in a single vertex count as one here.
  *   remove_degenerate: drops faces with a repeated vertex index, then unreferenced vertices.
  *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise quadric-error-metric edge collapse (the algorithm
  *                      class of upstream's MeshLab filter) in rounds of independent collapses: every vertex picks its

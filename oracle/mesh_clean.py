@@ -33,7 +33,7 @@ def remove_floaters(verts, faces, min_ratio=0.005):
     _, label = connected_components(coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(n, n)), directed=False)
     fl = label[f[:, 0]]
     counts = np.bincount(fl)
-    keep = counts[fl] >= max(1, int(np.ceil(min_ratio * counts.max())))
+    keep = counts[fl] >= max(1, int(min_ratio * counts.max()))     # truncation, as MeshLab's (unsigned)(largest * ratio)
     return _compact(v, f, keep)
 
 
