@@ -49,7 +49,7 @@ static bool g_overlap_mlp = true;     // single blocks: MLP-in GEMM on a second 
 static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
-static bool g_geo_fp8 = false;   // BASELINE.json configs[3]: the geo decoder's c_q / MLP GEMMs on fp8 (e4m3) operands; off by default
+static int g_geo_fp8 = 0;   // BASELINE.json configs[3]: geo decoder GEMMs on fp8 (e4m3) operands: 0 off (default) | 1 c_q + MLP | 2 MLP only | 3 c_q only
 constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP hidden: |GELU| up to 28 representable
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
@@ -713,7 +713,8 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         const int epi_x0 = xb ? EPI_BF16 : EPI_F32, epi_res = xb ? EPI_RESID_BF16 : EPI_RESID_F32;
         // fp8 mode (option geo_fp8, BASELINE.json configs[3]): LayerNorm writes e4m3 + row scales, c_q / c_fc / mlp.c_proj run
         // on fp8 operands; the attention, its output projection and the residual stream stay bf16
-        const bool f8 = g_geo_fp8 && xb && W % 256 == 0 && lfc.N % 256 == 0;
+        const bool f8 = g_geo_fp8 != 0 && xb && W % 256 == 0 && lfc.N % 256 == 0;
+        const bool f8q = f8 && g_geo_fp8 != 2, f8m = f8 && g_geo_fp8 != 3;
         uint8_t* xn8 = reinterpret_cast<uint8_t*>(m.xn);
         uint8_t* hid8 = reinterpret_cast<uint8_t*>(m.hid);
         if (f8 && !m.fp8_sa) {
@@ -722,7 +723,7 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_RC(fill_f32(m.fp8_sconst, m.qc, kGeoHiddenScale, s));
         }
         R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, epi_x0, nullptr, 0, 1, s));
-        if (f8) R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l1w, l1b, 1e-6f, s, xb));
+        if (f8q) R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l1w, l1b, 1e-6f, s, xb));
         else R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
         QkvSplitArgs q{};
         q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
@@ -734,11 +735,11 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
             R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
         }
-        if (f8) R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lcq, nullptr, 0, n, EPI_QKV, &q, QKV_Q_ONLY, s));
+        if (f8q) R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lcq, nullptr, 0, n, EPI_QKV, &q, QKV_Q_ONLY, s));
         else R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
         R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
         R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0, 1, s));
-        if (f8) {
+        if (f8m) {
             R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l3w, l3b, 1e-6f, s, xb));
             R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lfc, hid8, lfc.N, n, EPI_FP8_GELU_ERF, nullptr, 0, s));
             R3G_RC(gemm_fp8(m, hid8, m.fp8_sconst, lfp, m.f32a, W, n, epi_res, nullptr, 0, s));
@@ -1055,7 +1056,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
-    else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value != 0;
+    else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
     else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);

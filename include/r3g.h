@@ -255,8 +255,8 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_pipelined" (0), "attn_ablate"
  * (timing-only masks, results are garbage), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
- * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q / MLP GEMMs on e4m3
- * operands: a different precision, NOT result-preserving), "gemm_splitk" (0).  None of them changes a
+ * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
+ * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0).  None of them changes a
  * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation
  * (different rounding points inside the softmax). */
 int r3g_set_option(const char* name, int value);

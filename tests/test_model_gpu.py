@@ -338,13 +338,18 @@ def test_geo_decoder_fp8_mode(wide):
     out = torch.zeros(257 ** 3, device="cuda")
     wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
     bf16 = out[start:start + count].cpu().clone()
+    modes = {}
     try:
-        ffi.check(L.r3g_set_option(b"geo_fp8", 1))
-        out.zero_()
-        wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+        for mode in (3, 2, 1):          # c_q only, MLP only, both
+            ffi.check(L.r3g_set_option(b"geo_fp8", mode))
+            out.zero_()
+            wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+            modes[mode] = out[start:start + count].cpu().clone()
     finally:
         ffi.check(L.r3g_set_option(b"geo_fp8", 0))
-    fp8 = out[start:start + count].cpu()
+    for mode, name in ((3, "c_q only"), (2, "MLP only")):
+        report("  fp8 %s" % name, (modes[mode] - ref).abs().max().item() / ref.abs().max().item(), TOL["grid_logits_fp8"])
+    fp8 = modes[1]
     d = (fp8 - ref).abs().max().item() / ref.abs().max().item()
     report("full-width grid logits, geo decoder in fp8 mode (257^3 slice)", d, TOL["grid_logits_fp8"])
     report("  fp8 mode against the bf16 path", (fp8 - bf16).abs().max().item() / bf16.abs().max().item(), TOL["grid_logits_fp8"])
