@@ -3,6 +3,9 @@ set -x
 cd /root/repo
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/final_tests.log
 timeout 400 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+# not the headline: the fp8 mode of the geo decoder, and a configs[3]-shaped run (513^3 grid, fp8 geo decoder)
+timeout 300 python bench.py --fp8-geo --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/bench_fp8geo.json 2> gpurun_out/bench_fp8geo.err
+timeout 400 python bench.py --fp8-geo --octree-resolution 512 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err
 cd /tmp && export TMPDIR=/tmp
 R3G_OPTIONS=overlap_mlp=0 timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_final -o b -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /root/repo/gpurun_out/prof_final.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
