@@ -231,7 +231,7 @@ def main():
     strong = None
     if dist is not None:
         # strong scaling: configs[1]'s 8 crops in total, claimed dynamically (r3g.dist.WorkQueue), meshes gathered
-        total_s = 8
+        total_s = min(8, len(dev_crops))     # (8 unless a very short run broadcast fewer crops)
         q = rdist.WorkQueue(total_s, name="bench_strong")
         barrier()
         t1 = time.perf_counter()
