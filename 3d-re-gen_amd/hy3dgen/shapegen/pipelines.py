@@ -72,10 +72,11 @@ def config_from_yaml(doc):
 
 
 class Hunyuan3DDiTPipeline:
-    def __init__(self, cfg, state_dict, device="cuda", grid_chunk=0):
+    def __init__(self, cfg, state_dict, device="cuda", grid_chunk=0, private_ctx=False):
         dev = torch.device(device)
         self.cfg = cfg
         self.device = torch.device("cuda", dev.index or 0)
+        self.private_ctx = bool(private_ctx)     # own r3g_ctx: a second pipeline that runs beside another one on this GPU
         self.model = self._make_model(cfg, state_dict, grid_chunk)
         self.image_processor = ImageProcessorV2(**cfg["proc"])
         self.last_grid = None
@@ -84,13 +85,15 @@ class Hunyuan3DDiTPipeline:
     # The three places where this class touches the device.  (The API-contract test that runs the reference's stage
     # script on a machine without a GPU overrides exactly these; the product has no CPU path.)
     def _make_model(self, cfg, state_dict, grid_chunk):
-        return _model.ShapeModel(cfg, state_dict, self.device.index, grid_chunk=grid_chunk)
+        return _model.ShapeModel(cfg, state_dict, self.device.index, grid_chunk=grid_chunk,
+                                 private_ctx=getattr(self, "private_ctx", False))
 
     def _device_ctx(self):
         return torch.cuda.device(self.device)
 
     def _extract_mesh(self, grid, mc_level, box_v, octree_resolution):
-        return _mc.extract_mesh(grid, mc_level, box_v, octree_resolution)
+        return _mc.extract_mesh(grid, mc_level, box_v, octree_resolution,
+                                ctx=self.model.ctx if getattr(self, "private_ctx", False) else None)
 
     # ---- construction (same entry points as upstream) -------------------------------------------
     @classmethod

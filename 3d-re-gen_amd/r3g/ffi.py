@@ -117,6 +117,15 @@ def check(rc):
     raise R3GError(rc, msg)
 
 
+def new_context(device=0):
+    """A further r3g_ctx on a device: its own model slot and workspaces, for a second pipeline that runs concurrently with
+    the first (one context is not thread-safe; two are independent).  The caller keeps the handle."""
+    lib()
+    h = _P()
+    check(lib().r3g_create(int(device), ctypes.byref(h)))
+    return h
+
+
 def context(device=0):
     """The process-wide r3g_ctx of a device (created on first use)."""
     if device not in _CTX:

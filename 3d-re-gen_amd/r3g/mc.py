@@ -18,7 +18,7 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _run(grid, level, classic, xform, reverse):
+def _run(grid, level, classic, xform, reverse, ctx=None):
     if not isinstance(grid, torch.Tensor) or grid.ndim != 3:
         raise ValueError("Input volume should be a 3D torch tensor.")
     if not grid.is_cuda:
@@ -28,7 +28,7 @@ def _run(grid, level, classic, xform, reverse):
     grid = grid.contiguous().float()
     dev = grid.device.index or 0
     with torch.cuda.device(dev):
-        ctx = _l.context(dev)
+        ctx = ctx if ctx is not None else _l.context(dev)
         L = _l.lib()
         nv, nf = ctypes.c_int64(), ctypes.c_int64()
         _l.check(L.r3g_mc_count(ctx, grid.data_ptr(), grid.shape[0], grid.shape[1], grid.shape[2], float(level),
@@ -49,7 +49,7 @@ def marching_cubes(grid, level, use_classic=False):
     return _run(grid, level, use_classic, None, True)
 
 
-def extract_mesh(grid, mc_level=0.0, bounds=1.01, octree_resolution=None):
+def extract_mesh(grid, mc_level=0.0, bounds=1.01, octree_resolution=None, ctx=None):
     """Upstream MCSurfaceExtractor.run (+ the faces[:, ::-1] of export_to_trimesh) on one grid."""
     if octree_resolution is None:
         octree_resolution = grid.shape[0] - 1
@@ -57,4 +57,4 @@ def extract_mesh(grid, mc_level=0.0, bounds=1.01, octree_resolution=None):
         bounds = [-bounds, -bounds, -bounds, bounds, bounds, bounds]
     bmin, bmax = np.array(bounds[0:3], np.float64), np.array(bounds[3:6], np.float64)
     gs = np.array([int(octree_resolution) + 1] * 3, np.float64)  # upstream divides by R+1
-    return _run(grid, mc_level, False, (gs, bmax - bmin, bmin), False)
+    return _run(grid, mc_level, False, (gs, bmax - bmin, bmin), False, ctx)

@@ -93,12 +93,13 @@ def prepare_weights(sd, device):
 class ShapeModel:
     """Weights + activation arena of one shape model on one GPU."""
 
-    def __init__(self, cfg, state_dict, device=0, grid_chunk=0):
+    def __init__(self, cfg, state_dict, device=0, grid_chunk=0, private_ctx=False):
         if not torch.cuda.is_available():
             raise RuntimeError("r3g.ShapeModel needs an MI355X: libr3g has no CPU path")
         self.cfg = cfg
         self.device = torch.device("cuda", device)
-        self.ctx = _l.context(device)
+        self.private_ctx = bool(private_ctx)
+        self.ctx = _l.new_context(device) if private_ctx else _l.context(device)
         self.L = _l.lib()
         self._c = make_config(cfg, grid_chunk)
         with torch.cuda.device(self.device):
@@ -122,11 +123,12 @@ class ShapeModel:
             for name, v in self._scalars.items():
                 _l.check(self.L.r3g_model_set_scalar(self.ctx, name.encode(), v))
             torch.cuda.synchronize()
-        ShapeModel._current[self.device.index] = self
+        if not self.private_ctx:
+            ShapeModel._current[self.device.index] = self
         self._have_z = False
 
     def _activate(self):
-        if ShapeModel._current.get(self.device.index) is not self:
+        if not self.private_ctx and ShapeModel._current.get(self.device.index) is not self:
             self._install()
 
     def _s(self):

@@ -357,6 +357,48 @@ def test_geo_decoder_fp8_mode(wide):
     assert not torch.equal(fp8, bf16)                      # the mode really took the other path
 
 
+def test_two_pipelines_with_private_contexts_run_concurrently():
+    """jobs_per_gpu: two pipelines on one GPU, each with its own r3g_ctx and stream, driven by two host threads at the same
+    time, give bit-identical grids to a sequential run (one context is not thread-safe; two are independent)"""
+    import threading
+    import torch
+    from PIL import Image
+    from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
+    from oracle import hy3d_torch as H
+    cfg = H.tiny_config()
+    sd = bf16_round_matrices(H.synthetic_state_dict(cfg, seed=5))
+    pipes = [Hunyuan3DDiTFlowMatchingPipeline(cfg, sd, "cuda:0", grid_chunk=2048, private_ctx=True) for _ in range(2)]
+    rng = np.random.default_rng(0)
+    imgs = []
+    for k in range(2):
+        arr = np.zeros((80, 80, 4), np.uint8)
+        arr[20:60, 15:65, :3] = rng.integers(0, 255, (40, 50, 3))
+        arr[20:60, 15:65, 3] = 255
+        imgs.append(Image.fromarray(arr, "RGBA"))
+
+    def one(k, out):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(3):
+                pipes[k](image=imgs[k], num_inference_steps=3, octree_resolution=16, generator=torch.Generator().manual_seed(7))
+                torch.cuda.current_stream().synchronize()
+                out.append(pipes[k].last_grid.clone())
+    seq = [[], []]
+    one(0, seq[0])
+    one(1, seq[1])
+    con = [[], []]
+    th = [threading.Thread(target=one, args=(k, con[k])) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert len(con[k]) == 3
+        for a, b in zip(seq[k], con[k]):
+            assert torch.equal(a, b)
+    assert not torch.equal(seq[0][0], seq[1][0])
+
+
 def test_fused_and_unfused_paths_agree(tiny):
     """A/B switches: the QKV epilogue fusion and the batched modulation GEMV must reproduce the separate kernels."""
     import torch
