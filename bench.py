@@ -169,6 +169,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    # functional test of the N > 1 path on a one-GPU box: R3G_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and switches the
+    # process group to gloo (RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("R3G_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:   # the host-side preprocess of every rank shares the box's cores
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
@@ -176,7 +181,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
     from r3g import ffi
@@ -224,7 +232,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=rdist._comm_device(), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -245,7 +253,7 @@ def main():
         got = rdist.gather_meshes(mine, dst=0)
         torch.cuda.synchronize()
         barrier()
-        ts = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        ts = torch.tensor([time.perf_counter() - t1], device=rdist._comm_device(), dtype=torch.float64)
         dist.all_reduce(ts, op=dist.ReduceOp.MAX)
         if rank == 0:
             assert len(got) == total_s
