@@ -236,6 +236,14 @@ R3G_QEM_HD void best_partner(const MeshView& m, int v, int32_t* partner, uint64_
         for (int k = 0; k < 3; ++k) {
             const int u = f[k];
             if (u == v) continue;
+            // a neighbour shows up once per face around the edge (v, u): evaluate it for the first of them only (the ring's
+            // face indices are in cache; the evaluation gathers u's quadric and solves a 3x3 system)
+            bool dup = false;
+            for (uint32_t j = m.off[v]; j < i && !dup; ++j) {
+                const int32_t* g = m.faces + 3 * m.adj[j];
+                dup = g[0] == u || g[1] == u || g[2] == u;
+            }
+            if (dup) continue;
             const int lo = v < u ? v : u, hi = v < u ? u : v;
             // an interior vertex may merge INTO a boundary vertex (which stays put); two boundary vertices merge freely
             // along a boundary edge (the constraint planes in their quadrics keep the outline), never across the interior
