@@ -102,7 +102,7 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 // epilogue and wants it landed, but must not wait for the epilogue's own stores afterwards).
 template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
-                                              int wc, int lane, char* lds_wave = nullptr) {
+                                              int wc, int lane, char* lds_wave = nullptr, const f32x4* bias_pre = nullptr) {
     constexpr int WROWS = MI * 16;
     static_assert(MI % PI == 0 && (EPI != EPI_QKV || PI == MI), "scratch passes");
     if constexpr (EPI == EPI_QKV) {
@@ -484,7 +484,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         const int nc = n < p.N ? n : p.N - 4;  // clamped: loads are unconditional, only stores are predicated
         biasv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         gatev[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (bias_pre) biasv[j] = bias_pre[j];     // loaded by the caller before it issued other memory traffic
+        else if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
         if (EPI == EPI_RESID_F32 && gate) gatev[j] = *reinterpret_cast<const f32x4*>(gate + nc);
     }
     const int64_t cbase = (int64_t)batch * p.strideC;
@@ -1527,6 +1528,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         if (wr == 0) R3G_BAR();
 
         const Tile done = cur;
+        // the finished tile's bias goes first: a wait for it must not also wait for the LDS-DMA issued below (vmcnt is in
+        // order), and its latency hides under the staging (s_memtime: epilogue 10.4 k -> 8.5 k cycles)
+        f32x4 bias_pre[4];
+        {
+            const GemmArgs& pp = args_of(done.second);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = done.n0 + wc * 64 + ((lane >> 4) << 2) + j * 16;
+                bias_pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (pp.bias) bias_pre[j] = *reinterpret_cast<const f32x4*>(pp.bias + (n < pp.N ? n : pp.N - 4));
+            }
+        }
         my += nwg;
         const bool more = my < total_tiles;
         if (more) {
@@ -1538,7 +1551,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         {
             const GemmArgs& pp = args_of(done.second);
             gemm_epilogue<EPI, MI, true, 2>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane,
-                                            pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr);
+                                            pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr,
+                                            (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) ? bias_pre : nullptr);
         }
         if (!more) break;
         // the staging pointers are recomputed rather than kept alive across the epilogue (16 registers it needs); the
