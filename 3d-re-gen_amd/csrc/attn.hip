@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
 //  * 1-D grid, work items ordered head-major and cut into 8 contiguous runs, one per XCD (block b runs on XCD b % 8):
 //    an XCD walks the query tiles of one head after the other, so its K / V^T stay in its 4 MiB L2.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ float half_max(float x) {   // max over lanes q and q+32
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -511,7 +512,8 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return r;
 }
 
-constexpr float PSUM_LIMIT = 1024.f;   // a block whose 16 p of one lane sum to more (some p > 64) is re-stabilised
+constexpr float PSUM_LIMIT = 1024.f;   // (pipelined body) a block whose 16 p of one lane sum to more is re-stabilised
+constexpr float SCORE_LIMIT = 8.f;     // a block with a score more than 8 (log2 units) above its stabiliser (p > 256) is re-stabilised
 
 // D = A B + C with D in registers DISTINCT from C (hipcc ties vdst to srcC for the builtin and copies the 16 registers
 // of the stabiliser block first: 32 v_mov per key tile).  The s_nop covers a VALU write of an operand just before.
@@ -801,51 +803,40 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
                     else if (key == bias_key) s[r] += bias_l2;
                 }
             }
-            if (first_block) {   // the stabiliser starts as the exact maximum of the first 32 keys
-                float mx = s[0];
+            // lane maximum of the 16 scores (relative to the stabiliser): decides BEFORE the exponentials whether the block
+            // has to be re-stabilised, so that the rare path only rewrites values in place (O, l, the stabiliser block and
+            // the scores, all by arithmetic on themselves) and nothing computed on it is merged with a value of the common
+            // path afterwards -- with the test behind the exponentials (on their sum) the join copied 16 exponentials
+            // and the 16-register stabiliser block on the common path of every key block (32 v_mov)
+            float mx = fmaxf(s[0], s[1]);
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+            if (first_block) {   // the stabiliser starts as the exact maximum of the first 32 keys
                 m_run = half_max(mx);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
+            } else if (__any(!(mx <= SCORE_LIMIT))) {
+                // rare: some query's scores outgrew its stabiliser (or are NaN).  s is relative to the old one: the growth
+                // is the block maximum itself.  Nothing of this block has entered O or l yet.
+                const float grow = fmaxf(half_max(mx), 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-grow);
+                m_run += grow;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] -= grow; s[r] -= grow; }
             }
             float pe[16];
             uint32_t pk[8];
-            auto exponentiate = [&]() {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pe[r] = (ABL & 1) ? s[r] * 0.001f : __builtin_amdgcn_exp2f(s[r]);
+            for (int r = 0; r < 16; ++r) pe[r] = (ABL & 1) ? s[r] * 0.001f : __builtin_amdgcn_exp2f(s[r]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
-            };
-            float ps0, ps1;
-            auto row_sum = [&]() {
-                ps0 = 0.f;
-                ps1 = 0.f;
+            for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
+            {
+                f32x2 ps = (f32x2){pe[0], pe[1]};   // even / odd partial sums on the packed fp32 adder
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) { ps0 += pe[r]; ps1 += pe[r + 1]; }
-                ps0 += ps1;
-            };
-            exponentiate();
-            row_sum();
-            if (!first_block) {
-                // sum >= max: a small sum proves that no p is large (and inf / NaN fail the comparison)
-                if (__any(!(ps0 <= PSUM_LIMIT))) {
-                    // rare: some query's scores outgrew its stabiliser.  s is relative to the old one: the growth is the
-                    // block maximum itself.  Nothing of this block has entered O or l yet.
-                    float mx = s[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-                    const float grow = fmaxf(half_max(mx), 0.f);
-                    const float alpha = __builtin_amdgcn_exp2f(-grow);
-                    m_run += grow;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] = -m_run; s[r] -= grow; }
-                    exponentiate();
-                    row_sum();
-                }
+                for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
+                l_run += ps[0] + ps[1];
             }
-            l_run += ps0;
             // ---- O^T += V^T P^T for these 32 keys: the lane's 8 keys of each 16-key group are one 16-byte chunk of V^T
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -905,6 +896,236 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Third generation: 64 queries per wave.  The second-generation body with TWO 32-query blocks per wave that share every
+// K and V^T fragment read from LDS: a 32-key block costs a wave 8 ds_read_b128 for 16 MFMAs instead of 8 (at the matrix
+// pipe's peak rate the 32-query form asks LDS for 128 B/clk/CU, all the LDS has), a 256-query workgroup halves the
+// L2 -> LDS stream per query, and the two blocks give every MFMA chain an independent neighbour.  Two workgroups of four
+// waves per CU (256 registers per lane).  Per 32-query block the arithmetic, the order of the key blocks and the
+// re-stabilise decisions (taken per aligned group of 32 queries) are those of attn2_kernel: the outputs are bit-identical.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    constexpr int QT = NW * 64;
+    int b, hd, qt;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
+        const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + QT - 1) / QT;
+        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + QT - 1) / QT : 0) : ntq0;
+        const int per_head = p.ragged ? ntq0 + ntq1 : ntq0 * p.B;
+        hd = item / per_head;
+        int rem = item - hd * per_head;
+        if (p.ragged) {
+            b = rem >= ntq0 ? 1 : 0;
+            qt = rem - (b ? ntq0 : 0);
+        } else {
+            b = rem / ntq0;
+            qt = rem - b * ntq0;
+        }
+    }
+    const int q0 = qt * QT + wid * 64 + ql;   // query of block 0; block 1 holds query q0 + 32
+    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int kvb = p.kv_batch_stride_zero ? 0 : b;
+    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
+    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
+    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + qb * 32;
+        const int qrow = q < p.Lq_pad ? q : p.Lq_pad - 1;   // a 256-query tile may reach past the 128-aligned allocation
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qrow * 64 + ks * 16 + hh * 8);
+    }
+    if (!p.q_prescaled) {
+        const float sc = p.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { bf16x8 v; uint32_t u[4]; } w;
+                w.v = qf[qb][ks];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w.u[e] = pack_bf16(__uint_as_float(w.u[e] << 16) * sc, __uint_as_float(w.u[e] & 0xFFFF0000u) * sc);
+                qf[qb][ks] = w.v;
+            }
+    }
+
+    f32x16 o[2][2], negm[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+
+    int off[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int row = rb * 32 + ql;
+        off[rb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);
+    }
+
+    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
+    const int bias_key = p.ragged ? p.bias_key[b] : -1;
+    const float bias_l2 = p.ragged ? p.bias_log2[b] : 0.f;
+    constexpr int PPW = 8 / NW;
+    int koff[PPW], voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wid * PPW + i) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);
+        koff[i] = row * 64 + kc * 8;
+        voff[i] = row * p.Lk_pad + kc * 8;
+    }
+    auto stage = [&](int t, char* dst) {
+        const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
+        const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + (wid * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + TILE_B + (wid * PPW + i) * 1024),
+                                             16, 0, 0);
+        }
+    };
+    const bool pad_tail = ntiles * KV_TILE > Lk;
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tile = [&](auto masked, auto first, const int t) {
+        const char* cur = smem + (t & 1) * STAGE_B;
+        if (t + 1 < ntiles) stage(t + 1, smem + ((t + 1) & 1) * STAGE_B);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            constexpr bool kFirst = decltype(first)::value;
+            const bool first_block = kFirst && kb == 0;
+            // ---- scores of 32 keys for both query blocks from one set of K fragments
+            bf16x8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(cur + (off[kb] ^ (ks << 5)));
+            f32x16 s[2];
+            if (first_block) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], z, 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][0], z, 0, 0, 0);
+            } else {
+                s[0] = mfma_32x32x16_fresh(kf[0], qf[0][0], negm[0]);
+                s[1] = mfma_32x32x16_fresh(kf[0], qf[1][0], negm[1]);
+            }
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) {
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[0][ks], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[1][ks], s[1], 0, 0, 0);
+            }
+            uint32_t pk[2][8];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16& sq = s[qb];
+                if constexpr (decltype(masked)::value) {
+                    const int key_base = t * KV_TILE + kb * 32 + 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key_base + (r & 3) + 8 * (r >> 2);
+                        if (key >= Lk) sq[r] = -INFINITY;
+                        else if (key == bias_key) sq[r] += bias_l2;
+                    }
+                }
+                float mx = fmaxf(sq[0], sq[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sq[r]), sq[r + 1]);
+                if (first_block) {
+                    m_run[qb] = half_max(mx);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { negm[qb][r] = -m_run[qb]; sq[r] -= m_run[qb]; }
+                } else if (__any(!(mx <= SCORE_LIMIT))) {
+                    const float grow = fmaxf(half_max(mx), 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-grow);
+                    m_run[qb] += grow;
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        o[qb][0][r] *= alpha;
+                        o[qb][1][r] *= alpha;
+                        negm[qb][r] -= grow;
+                        sq[r] -= grow;
+                    }
+                }
+                float pe[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(sq[r]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[qb][e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
+                f32x2 ps = (f32x2){pe[0], pe[1]};
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
+                l_run[qb] += ps[0] + ps[1];
+            }
+            // ---- O^T += V^T P^T: one V^T fragment feeds both query blocks
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                union { uint32_t u[4]; bf16x8 v; } pf[2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pf[qb].u[e] = pk[qb][4 * ks2 + e];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
+                    o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0].v, o[0][db], 0, 0, 0);
+                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1].v, o[1][db], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    if (ntiles == 1) {
+        if (pad_tail) tile(std::true_type{}, std::true_type{}, 0);
+        else tile(std::false_type{}, std::true_type{}, 0);
+    } else {
+        tile(std::false_type{}, std::true_type{}, 0);
+        for (int t = 1; t < ntiles - 1; ++t) tile(std::false_type{}, std::false_type{}, t);
+        if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1);
+        else tile(std::false_type{}, std::false_type{}, ntiles - 1);
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + qb * 32;
+        const float inv = 1.0f / half_sum(l_run[qb]);
+        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
+        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        uint16_t* dst = p.O + orow + hd * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint2 even, odd;
+                even.x = pack_bf16(o[qb][db][8 * gp] * inv, o[qb][db][8 * gp + 1] * inv);
+                even.y = pack_bf16(o[qb][db][8 * gp + 2] * inv, o[qb][db][8 * gp + 3] * inv);
+                odd.x = pack_bf16(o[qb][db][8 * gp + 4] * inv, o[qb][db][8 * gp + 5] * inv);
+                odd.y = pack_bf16(o[qb][db][8 * gp + 6] * inv, o[qb][db][8 * gp + 7] * inv);
+                const u32x2 rx = __builtin_amdgcn_permlane32_swap(even.x, odd.x, false, false);
+                const u32x2 ry = __builtin_amdgcn_permlane32_swap(even.y, odd.y, false, false);
+                uint4 out;
+                out.x = rx[0]; out.y = ry[0]; out.z = rx[1]; out.w = ry[1];
+                if (q < Lq) *reinterpret_cast<uint4*>(dst + db * 32 + 16 * gp + 8 * hh) = out;
+            }
+    }
+}
+
 }  // namespace
 
 static bool g_attn_glds = true;
@@ -914,8 +1135,12 @@ void attn_set_ablate(int mask) { g_attn_ablate = mask; }
 void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 
-static int g_attn_gen = 2;
-void attn_set_generation(int gen) { if (gen >= 1 && gen <= 5) g_attn_gen = gen; }
+static int g_attn_gen = 7;
+// generation 7 takes the 64-query-per-wave kernel where its 256-query workgroups make at least four full rounds of the
+// 512 slots (the geo decoder's 131072-query passes: +6 %); on the DiT's 4442-query attention the coarser grid costs more
+// than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
+constexpr int kWide6MinItems = 2048;
+void attn_set_generation(int gen) { if (gen >= 1 && gen <= 7) g_attn_gen = gen; }
 float attn_q_scale(float scale) { return g_attn_gen >= 2 ? scale * 1.4426950408889634f : 1.0f; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
@@ -937,13 +1162,19 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     }
     ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
     if (g_attn_gen >= 2 && !g_attn_pipelined) {
-        // generation: 2 = 4 waves, 3 = 4 waves software-pipelined, 4 = 8 waves software-pipelined, 5 = 8 waves
-        const int nw = (g_attn_glds && g_attn_gen >= 4) ? 8 : 4, qtile = nw * 32;
-        int items = 0;
-        if (p.ragged) for (int b = 0; b < p.B; ++b) items += (p.lq_b[b] + qtile - 1) / qtile;
-        else items = ((p.Lq + qtile - 1) / qtile) * p.B;
-        items *= p.H;
-        if (g_attn_ablate && g_attn_gen == 2) {
+        // generation: 2 = 4 waves of 32 queries, 3 = 2 software-pipelined, 4 = 8 waves software-pipelined, 5 = 8 waves,
+        // 6 = 4 waves of 64 queries, 7 = 6 where its 256-query workgroups fill the two slots per CU, otherwise 2
+        auto count = [&](int qtile) {
+            int n = 0;
+            if (p.ragged) for (int b = 0; b < p.B; ++b) n += (p.lq_b[b] + qtile - 1) / qtile;
+            else n = ((p.Lq + qtile - 1) / qtile) * p.B;
+            return n * p.H;
+        };
+        int gen = g_attn_gen;
+        if (gen == 7) gen = (g_attn_glds && count(256) >= kWide6MinItems) ? 6 : 2;
+        const int qtile = (g_attn_glds && gen >= 4) ? 256 : 128;
+        const int items = count(qtile);
+        if (g_attn_ablate && gen == 2) {
             switch (g_attn_ablate) {
 #define R3G_ABL2(m) case m: hipLaunchKernelGGL((attn2_kernel<true, false, 4, m>), dim3(items), dim3(256), 0, s, p); break;
                 R3G_ABL2(1) R3G_ABL2(4) R3G_ABL2(8) R3G_ABL2(12) R3G_ABL2(16) R3G_ABL2(48) R3G_ABL2(64) R3G_ABL2(128)
@@ -954,9 +1185,10 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
             return hipGetLastError();
         }
         if (!g_attn_glds) hipLaunchKernelGGL((attn2_kernel<false, false, 4>), dim3(items), dim3(256), 0, s, p);
-        else if (g_attn_gen == 3) hipLaunchKernelGGL((attn2_kernel<true, true, 4>), dim3(items), dim3(256), 0, s, p);
-        else if (g_attn_gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
-        else if (g_attn_gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
+        else if (gen == 3) hipLaunchKernelGGL((attn2_kernel<true, true, 4>), dim3(items), dim3(256), 0, s, p);
+        else if (gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
+        else if (gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
+        else if (gen == 6) hipLaunchKernelGGL((attn3_kernel<4>), dim3(items), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
         return hipGetLastError();
     }

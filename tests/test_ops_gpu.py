@@ -181,7 +181,30 @@ def test_attention(env, dma, B, H, Lq, Lk, shared):
     assert rel_l2(o.float(), ref) <= 1e-2
 
 
-def test_attention_forced_rescale(env):
+@pytest.mark.parametrize("B,H,Lq,Lk,shared", [(1, 2, 200, 200, 0), (2, 16, 4442, 4442, 0), (3, 4, 500, 3072, 1),
+                                              (1, 3, 26, 26, 0), (1, 2, 1000, 64, 0)])
+def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, shared):
+    """attn_generation 6 (64 queries per wave, K / V^T fragments shared by two 32-query blocks) makes every decision per
+    aligned group of 32 queries like the default kernel: same bits, and the same tolerance against the fp32 reference"""
+    torch, L, ffi = env
+    Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, shared, Lq + 3 * Lk)
+    outs = []
+    try:
+        for gen in (2, 6):
+            ffi.check(L.r3g_set_option(b"attn_generation", gen))
+            o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
+            ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp,
+                                         shared, 1, stream(torch)))
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        ffi.check(L.r3g_set_option(b"attn_generation", 7))
+    assert rel_l2(outs[1].float(), ref) <= 1e-2
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("gen", [2, 6])
+def test_attention_forced_rescale(env, gen):
     """One key row spiked against one query so the running max jumps late in the sequence
     (exercises the online-softmax rescale branch with a large factor)."""
     torch, L, ffi = env
@@ -193,8 +216,13 @@ def test_attention_forced_rescale(env):
     ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float(), vrows)
     ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, 64)
     o = torch.zeros(B, Lq, 64, device="cuda", dtype=torch.bfloat16)
-    ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, 0, 1,
-                                 stream(torch)))
+    ffi.check(L.r3g_set_option(b"attn_generation", gen))
+    try:
+        ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, 0, 1,
+                                     stream(torch)))
+        torch.cuda.synchronize()
+    finally:
+        ffi.check(L.r3g_set_option(b"attn_generation", 7))
     assert rel_l2(o.float(), ref) <= 1e-2
     assert torch.allclose(o.float()[0, 5], vrows[0, 0, 400], atol=3e-2)
 

@@ -55,6 +55,17 @@ def main():
                 ffi.check(L.r3g_set_option(b"attn_ablate", mask))
             ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp,
                                          shared, 1, s))
+        if a.gens:   # bit-comparison of every generation's output with the first one's
+            outs = {}
+            for m in masks:
+                o.zero_()
+                run(m)
+                torch.cuda.synchronize()
+                outs[m] = o.clone()
+            for m in masks[1:]:
+                d = (outs[m].float() - outs[masks[0]].float()).abs()
+                print(json.dumps(dict(op="attn_compare", shape=[B, H, Lq, Lk], gen=m, against=masks[0],
+                                      differing=int((outs[m] != outs[masks[0]]).sum()), max_abs=float(d.max()))), flush=True)
         times = {m: [] for m in masks}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for rnd in range(a.rounds + 1):
@@ -73,7 +84,7 @@ def main():
             print(json.dumps(dict(op="attn", B=B, H=H, Lq=Lq, Lk=Lk, zero=a.zero, **({"gen": m} if a.gens else {"gen": a.gen, "ablate": m}), us_med=1e3 * med, us_min=1e3 * min(ts),
                                   tflops_med=fl / med / 1e9)), flush=True)
     ffi.check(L.r3g_set_option(b"attn_ablate", 0))
-    ffi.check(L.r3g_set_option(b"attn_generation", 2))
+    ffi.check(L.r3g_set_option(b"attn_generation", 7))
 
 
 if __name__ == "__main__":
