@@ -45,7 +45,9 @@ struct Lin {
 
 static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-static bool g_overlap_mlp = true;     // single blocks: MLP-in GEMM on a second stream beside the attention kernel
+// single blocks: MLP-in GEMM on a second stream beside the attention kernel.  Off since the GEMM became a persistent grid of
+// one 160 KiB-LDS workgroup per CU: the two kernels can no longer share a CU and take turns (measured 1.4 % slower with it)
+static bool g_overlap_mlp = false;
 static bool g_group_streams = true;   // img + txt GEMMs of a double block in one launch
 static bool g_fuse_qkv = true;    // QKV split + q/k norm + V transpose in the projection's epilogue
 static bool g_batch_mods = true;  // one GEMV launch for all modulations of a DiT forward
@@ -515,8 +517,9 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
     const int seg_s[3][4] = {{0, T, 0, 0}, {T, T + 1, 1, Nl}, {R1, R1 + Nl, 1, 0}};
     // Single blocks: linear1 = [qkv | mlp-in].  The attention grid (960 workgroups of unequal length on 768 slots)
     // leaves a fifth of the machine idle in its second dispatch round; the MLP half of linear1 does not depend on the
-    // attention, so it is issued on a second stream (fork after the LayerNorm, join before linear2) and fills those
-    // slots.  Same kernels, same operands: the result does not change.
+    // attention, so it CAN be issued on a second stream (fork after the LayerNorm, join before linear2; option
+    // overlap_mlp).  Same kernels, same operands: the result does not change.  It paid (-1.1 %) while that GEMM ran
+    // 64 KiB workgroups that fit beside attention workgroups; the persistent 256x256 kernel owns a whole CU's LDS.
     const bool overlap = g_overlap_mlp && c.dit_depth_single > 0;
     if (overlap && !m.aux) {
         R3G_TRY(hipStreamCreateWithFlags(&m.aux, hipStreamNonBlocking));

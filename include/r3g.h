@@ -246,7 +246,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
 /* A/B switches for tests and ablations.  Default 1: "fuse_qkv" (QKV split/norm/transpose in the projection epilogue
  * vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch), "lds_dma"
  * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
- * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (MLP half of a single block's linear1
+ * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (0 default | 1: MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
  * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 two-stage | 10 = 256x128 | 11 = 256x256 phased | 12 = phased,
  * persistent grid | 13 = phased, deterministic split-K over two workgroups per tile | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"

@@ -474,12 +474,12 @@ def test_grouped_stream_launches_are_bit_identical(which, tiny, wide):
     finally:
         ffi.check(L.r3g_set_option(b"group_streams", 1))
     assert torch.equal(a, b)
-    # the MLP half of linear1 on a second stream beside the attention kernel: scheduling only
+    # the MLP half of linear1 on a second stream beside the attention kernel (optional, off by default): scheduling only
     try:
-        ffi.check(L.r3g_set_option(b"overlap_mlp", 0))
+        ffi.check(L.r3g_set_option(b"overlap_mlp", 1))
         c = st.gpu.flow_sample(lat0.clone(), cond, 2, 5.0).clone()
     finally:
-        ffi.check(L.r3g_set_option(b"overlap_mlp", 1))
+        ffi.check(L.r3g_set_option(b"overlap_mlp", 0))
     assert torch.equal(a, c)
     for _ in range(3):                                   # and it is stable from run to run
         assert torch.equal(a, st.gpu.flow_sample(lat0.clone(), cond, 2, 5.0))

@@ -7,9 +7,9 @@ timeout 400 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_fi
 timeout 300 python bench.py --fp8-geo --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/bench_fp8geo.json 2> gpurun_out/bench_fp8geo.err
 timeout 400 python bench.py --fp8-geo --octree-resolution 512 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err
 cd /tmp && export TMPDIR=/tmp
-R3G_OPTIONS=overlap_mlp=0 timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_final -o b -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /root/repo/gpurun_out/prof_final.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_final -o b -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /root/repo/gpurun_out/prof_final.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  R3G_OPTIONS=overlap_mlp=0 timeout 300 rocprofv3 --pmc $c --kernel-include-regex "gemm|attn|layernorm|ln_dot|mc_classify" --output-format csv -d /root/repo/gpurun_out/pmc_$c -o p -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --inference-steps 2 > /root/repo/gpurun_out/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex "gemm|attn|layernorm|ln_dot|mc_classify" --output-format csv -d /root/repo/gpurun_out/pmc_$c -o p -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --inference-steps 2 > /root/repo/gpurun_out/pmc_$c.log 2>&1
 done
 cd /root/repo
 DB=$(ls gpurun_out/prof_final/*/*_results.db gpurun_out/prof_final/*_results.db 2>/dev/null | head -1)
