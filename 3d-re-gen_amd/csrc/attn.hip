@@ -815,7 +815,8 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
                 m_run = half_max(mx);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
-            } else if (__any(!(mx <= SCORE_LIMIT))) {
+            } else if (__any(q < Lq && !(mx <= SCORE_LIMIT))) {
+                // (rows past Lq hold stale data: they must not decide anything, or a valid query's rounding would depend on it)
                 // rare: some query's scores outgrew its stabiliser (or are NaN).  s is relative to the old one: the growth
                 // is the block maximum itself.  Nothing of this block has entered O or l yet.
                 const float grow = fmaxf(half_max(mx), 0.f);
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
                     m_run[qb] = half_max(mx);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { negm[qb][r] = -m_run[qb]; sq[r] -= m_run[qb]; }
-                } else if (__any(!(mx <= SCORE_LIMIT))) {
+                } else if (__any(q0 + qb * 32 < Lq && !(mx <= SCORE_LIMIT))) {   // rows past Lq (stale data) decide nothing
                     const float grow = fmaxf(half_max(mx), 0.f);
                     const float alpha = __builtin_amdgcn_exp2f(-grow);
                     m_run[qb] += grow;

@@ -204,6 +204,30 @@ def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, sh
 
 
 @pytest.mark.parametrize("gen", [2, 6])
+def test_attention_ignores_stale_rows_past_lq(env, gen):
+    """The query rows between Lq and the padded length hold whatever an earlier launch left there.  They are computed and
+    dropped; they must not steer the wave-uniform re-stabilise branch either, or the rounding of the valid queries of
+    the same wave would depend on stale data (seen as a first-run / later-run difference in the pipeline)."""
+    torch, L, ffi = env
+    B, H, Lq, Lk = 1, 2, 200, 300
+    Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, 0, 5)
+    outs = []
+    ffi.check(L.r3g_set_option(b"attn_generation", gen))
+    try:
+        for junk in (0.0, 40.0, -40.0):
+            Q[:, :, Lq:] = junk
+            o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
+            ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, 0, 1,
+                                         stream(torch)))
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        ffi.check(L.r3g_set_option(b"attn_generation", 7))
+    assert rel_l2(outs[0].float(), ref) <= 1e-2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("gen", [2, 6])
 def test_attention_forced_rescale(env, gen):
     """One key row spiked against one query so the running max jumps late in the sequence
     (exercises the online-softmax rescale branch with a large factor)."""
