@@ -30,97 +30,142 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 // ---------------------------------------------------------------- LayerNorm (+affine) (+adaLN modulate) -> bf16
 constexpr int LN_MAX_V4 = 8;  // up to C = 64*4*8 = 2048
-// four consecutive elements of a row held as f32 (XBF16 = false) or bf16 (true)
+// four consecutive elements of a row held as f32 (XBF16 = false) or bf16 (true), as they sit in memory (the conversion of a prefetched row must not sit next to its load: it
+// would wait for the data at once)
+template <bool XBF16> struct Row4Raw { typedef float4 type; };
+template <> struct Row4Raw<true> { typedef uint2 type; };
 template <bool XBF16>
-__device__ __forceinline__ float4 load_row4(const float* base, int64_t elem) {
-    if constexpr (XBF16) {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
-        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-                           __uint_as_float(u.y & 0xFFFF0000u));
-    } else {
-        return *reinterpret_cast<const float4*>(base + elem);
-    }
+__device__ __forceinline__ typename Row4Raw<XBF16>::type load_row4_raw(const float* base, int64_t elem) {
+    if constexpr (XBF16) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    else return *reinterpret_cast<const float4*>(base + elem);
+}
+__device__ __forceinline__ float4 row4_cvt(const float4& r) { return r; }
+__device__ __forceinline__ float4 row4_cvt(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
 }
 
-template <bool XBF16>
+// One wave per row, the row held in registers.
+// NV: float4 per lane as a COMPILE-TIME constant (C = 256 NV; 0 = any C % 256 == 0 up to 2048, decided at run time).
+//   With a run-time count every `if (i < nv)` and every optional operand (`if (p.w)` ...) is a branch around a load, and
+//   the compiler closes each with s_waitcnt vmcnt(0): the loads of a row went out ONE PER MEMORY LATENCY (round 2's ISA:
+//   global_load, vmcnt(0), branch, global_load, ...).  With NV fixed the row's loads are issued back to back, and the
+//   optional operands are fetched in four straight-line groups up front.
+// RPW: rows per wave, one after the other, the next row's loads in flight while the current one is reduced and written: a
+//   workgroup of 4 rows lives ~6 us however little it does (dispatch, kernarg fetch, exit), which at 131 072 rows per
+//   launch is as long as its memory time; 4 x RPW rows per workgroup amortise it.
+// The arithmetic per row (element -> lane map, order of every sum) is the same in all instantiations.
+template <bool XBF16, int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
+    constexpr int NVC = NV ? NV : LN_MAX_V4;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = NV ? NV : (p.C >> 8);
+    typedef typename Row4Raw<XBF16>::type Raw;
+    float4 v[NVC];
+    Raw vr[NVC];
+    auto load = [&](int r) {
+        const int bt = r / p.rows_per_batch, lr = r - bt * p.rows_per_batch;
+        const int64_t xr = (int64_t)bt * p.x_batch_stride + (int64_t)lr * p.ldx;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) vr[i] = load_row4_raw<XBF16>(p.x, xr + (i * 64 + lane) * 4);
+    };
+    int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row >= p.rows) return;
-    const int batch = row / p.rows_per_batch, lrow = row - batch * p.rows_per_batch;
-    const int64_t xrow = (int64_t)batch * p.x_batch_stride + (int64_t)lrow * p.ldx;
-    const int nv = p.C >> 8;  // float4 per lane (C % 256 == 0) -- handled by launcher for other C via scalar path
-    float4 v[LN_MAX_V4];
-    float s = 0.f;
+    load(row);
+    // the affine weights do not depend on the row: fetched once per wave
+    float4 wv[NVC], bv[NVC];
+    if (p.w) {
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            v[i] = load_row4<XBF16>(p.x, xrow + (i * 64 + lane) * 4);
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
-    const float mean = wave_sum(s) / (float)p.C;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            ss += a * a + b * b + c * c + d * d;
-        }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
-    const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave)
-    const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
-    const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
-    uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
-    const bool to_fp8 = p.y8 != nullptr;      // wave-uniform
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            const int c = (i * 64 + lane) * 4;
-            float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
-            if (p.w) {
-                const float4 w = *reinterpret_cast<const float4*>(p.w + c);
-                o[0] *= w.x; o[1] *= w.y; o[2] *= w.z; o[3] *= w.w;
-            }
-            if (p.b) {
-                const float4 b = *reinterpret_cast<const float4*>(p.b + c);
-                o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
-            }
-            if (sc) {
-                const float4 a = *reinterpret_cast<const float4*>(sc + c);
-                o[0] *= 1.f + a.x; o[1] *= 1.f + a.y; o[2] *= 1.f + a.z; o[3] *= 1.f + a.w;
-            }
-            if (sh) {
-                const float4 a = *reinterpret_cast<const float4*>(sh + c);
-                o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
-            }
-            if (to_fp8) {   // keep the finished values (the row's maximum decides their scale), write below
-                v[i] = make_float4(o[0], o[1], o[2], o[3]);
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-                continue;
-            }
-            uint2 pk;
-            pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-            pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-            *reinterpret_cast<uint2*>(y + c) = pk;
-        }
-    if (to_fp8) {
-        // e4m3 operand of an fp8 GEMM: q = round(o / scale), scale = amax / 448 (one per row: the row is all here)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
-        const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-        const float inv = 1.0f / sc;
-        if (lane == 0) p.y_scale[row] = sc;
-        uint8_t* y8 = p.y8 + (int64_t)row * p.ldy8;
-#pragma unroll
-        for (int i = 0; i < LN_MAX_V4; ++i)
-            if (i < nv) {
-                int w = 0;
-                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, w, false);
-                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w, true);
-                *reinterpret_cast<uint32_t*>(y8 + (i * 64 + lane) * 4) = (uint32_t)w;
-            }
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) wv[i] = *reinterpret_cast<const float4*>(p.w + (i * 64 + lane) * 4);
     }
+    if (p.b) {
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) bv[i] = *reinterpret_cast<const float4*>(p.b + (i * 64 + lane) * 4);
+    }
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr, ++row) {
+        const bool more = RPW > 1 && rr + 1 < RPW && row + 1 < p.rows;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) v[i] = row4_cvt(vr[i]);
+        const int batch = row / p.rows_per_batch, lrow = row - batch * p.rows_per_batch;
+        const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave at a time)
+        const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
+        const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
+        float4 av[NVC], hv[NVC];
+        if (sc) {
+#pragma unroll
+            for (int i = 0; i < NVC; ++i)
+                if (NV || i < nv) av[i] = *reinterpret_cast<const float4*>(sc + (i * 64 + lane) * 4);
+        }
+        if (sh) {
+#pragma unroll
+            for (int i = 0; i < NVC; ++i)
+                if (NV || i < nv) hv[i] = *reinterpret_cast<const float4*>(sh + (i * 64 + lane) * 4);
+        }
+        if (more) load(row + 1);   // youngest loads of the iteration: the counted waits for the operands above leave them in flight
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        const float mean = wave_sum(s) / (float)p.C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                ss = fmaf(d, d, fmaf(c, c, fmaf(b, b, fmaf(a, a, ss))));   // spelled out: see the note on contraction below
+            }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
+        uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
+        const bool to_fp8 = p.y8 != nullptr;      // wave-uniform
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+                // every product and sum rounded on its own (__fmul_rn / __fadd_rn are never contracted): whether the
+                // compiler fuses `o * w + b` depends on the control flow around it, which differs between instantiations
+                if (p.w) { o[0] = __fmul_rn(o[0], wv[i].x); o[1] = __fmul_rn(o[1], wv[i].y); o[2] = __fmul_rn(o[2], wv[i].z); o[3] = __fmul_rn(o[3], wv[i].w); }
+                if (p.b) { o[0] = __fadd_rn(o[0], bv[i].x); o[1] = __fadd_rn(o[1], bv[i].y); o[2] = __fadd_rn(o[2], bv[i].z); o[3] = __fadd_rn(o[3], bv[i].w); }
+                if (sc) {
+                    o[0] = __fmul_rn(o[0], __fadd_rn(1.f, av[i].x)); o[1] = __fmul_rn(o[1], __fadd_rn(1.f, av[i].y));
+                    o[2] = __fmul_rn(o[2], __fadd_rn(1.f, av[i].z)); o[3] = __fmul_rn(o[3], __fadd_rn(1.f, av[i].w));
+                }
+                if (sh) { o[0] = __fadd_rn(o[0], hv[i].x); o[1] = __fadd_rn(o[1], hv[i].y); o[2] = __fadd_rn(o[2], hv[i].z); o[3] = __fadd_rn(o[3], hv[i].w); }
+                if (to_fp8) {   // keep the finished values (the row's maximum decides their scale), write below
+                    v[i] = make_float4(o[0], o[1], o[2], o[3]);
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    continue;
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+                pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+                *reinterpret_cast<uint2*>(y + c) = pk;
+            }
+        if (to_fp8) {
+            // e4m3 operand of an fp8 GEMM: q = round(o / scale), scale = amax / 448 (one per row: the row is all here)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+            const float qs = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+            const float inv = 1.0f / qs;
+            if (lane == 0) p.y_scale[row] = qs;
+            uint8_t* y8 = p.y8 + (int64_t)row * p.ldy8;
+#pragma unroll
+            for (int i = 0; i < NVC; ++i)
+                if (NV || i < nv) {
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w, true);
+                    *reinterpret_cast<uint32_t*>(y8 + (i * 64 + lane) * 4) = (uint32_t)w;
+                }
+        }
+        if (!more) break;
+    }   // rows of this wave
 }
 
 // generic-C variant (C % 64 == 0, C <= 2048): scalar per-lane elements (tiny configs, C = 64 / 128)
@@ -382,49 +427,75 @@ __global__ void fourier_grid_kernel(uint16_t* out, int64_t start, int count, int
     for (int c = dim; c < 64; ++c) o[c] = 0;
 }
 
-template <bool XBF16>
+template <bool XBF16, int NV, int RPW>
 __global__ __launch_bounds__(256) void ln_dot_kernel(const float* x, int64_t ldx, int rows, int C, int do_ln,
                                                      const float* lnw, const float* lnb, float eps, const float* w,
                                                      float b, float* out) {
-    // one wave per row, the row held in registers (C % 256 == 0, C <= 2048): one HBM pass
+    // a wave takes RPW rows one after the other, the row held in registers (C % 256 == 0, C <= 2048): one HBM pass, the
+    // next row's loads in flight behind the current row's reductions; NV as in layernorm_kernel
+    constexpr int NVC = NV ? NV : LN_MAX_V4;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = NV ? NV : (C >> 8);
+    typedef typename Row4Raw<XBF16>::type Raw;
+    float4 v[NVC];
+    Raw vr[NVC];
+    auto load = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) vr[i] = load_row4_raw<XBF16>(x, (int64_t)r * ldx + (i * 64 + lane) * 4);
+    };
+    int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row >= rows) return;
-    const int nv = C >> 8;
-    float4 v[LN_MAX_V4];
-    float s = 0.f;
+    load(row);
+    const bool affine = do_ln && lnw;
+    float4 gv[NVC], hv[NVC], ww[NVC];
+    if (affine) {
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            v[i] = load_row4<XBF16>(x, (int64_t)row * ldx + (i * 64 + lane) * 4);
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
-    float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-            ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-        }
-    float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-    if (!do_ln) { mean = 0.f; rstd = 1.f; }
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv) {
-            const int c = (i * 64 + lane) * 4;
-            float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
-            if (do_ln && lnw) {
-                const float4 g = *reinterpret_cast<const float4*>(lnw + c);
-                const float4 h = *reinterpret_cast<const float4*>(lnb + c);
-                o[0] = o[0] * g.x + h.x; o[1] = o[1] * g.y + h.y; o[2] = o[2] * g.z + h.z; o[3] = o[3] * g.w + h.w;
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) {
+                gv[i] = *reinterpret_cast<const float4*>(lnw + (i * 64 + lane) * 4);
+                hv[i] = *reinterpret_cast<const float4*>(lnb + (i * 64 + lane) * 4);
             }
-            const float4 ww = *reinterpret_cast<const float4*>(w + c);
-            acc += o[0] * ww.x + o[1] * ww.y + o[2] * ww.z + o[3] * ww.w;
-        }
-    acc = wave_sum(acc);
-    if (lane == 0) out[row] = acc + b;
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; ++i)
+        if (NV || i < nv) ww[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr, ++row) {
+        const bool more = RPW > 1 && rr + 1 < RPW && row + 1 < rows;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) v[i] = row4_cvt(vr[i]);
+        if (more) load(row + 1);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        float mean = wave_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                ss = fmaf(a3, a3, fmaf(a2, a2, fmaf(a1, a1, fmaf(a0, a0, ss))));
+            }
+        float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+        if (!do_ln) { mean = 0.f; rstd = 1.f; }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVC; ++i)
+            if (NV || i < nv) {
+                float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+                if (affine) {
+                    o[0] = fmaf(o[0], gv[i].x, hv[i].x); o[1] = fmaf(o[1], gv[i].y, hv[i].y);
+                    o[2] = fmaf(o[2], gv[i].z, hv[i].z); o[3] = fmaf(o[3], gv[i].w, hv[i].w);
+                }
+                acc += fmaf(o[3], ww[i].w, fmaf(o[2], ww[i].z, fmaf(o[1], ww[i].y, __fmul_rn(o[0], ww[i].x))));
+            }
+        acc = wave_sum(acc);
+        if (lane == 0) out[row] = acc + b;
+        if (!more) break;
+    }   // rows of this wave
 }
 
 // generic-C fallback (C % 64 == 0)
@@ -483,6 +554,30 @@ inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 }  // namespace
 
+// instantiations: C = 1024 (DiT, VAE, geo decoder) and 1536 (DINOv2-g) with the count fixed, anything else at run time
+#define R3G_LN_LAUNCH(XB)                                                                                                  \
+    {                                                                                                                      \
+        const bool r4 = ln_rows_per_wave(p.rows) == 4;                                                                     \
+        const dim3 g1((p.rows + 3) / 4), g4((p.rows + 15) / 16), blk(256);                                                 \
+        if (p.C == 1024 && g_ln_fixed) {                                                                                   \
+            if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 4, 4>), g4, blk, 0, s, p);                                    \
+            else hipLaunchKernelGGL((layernorm_kernel<XB, 4, 1>), g1, blk, 0, s, p);                                       \
+        } else if (p.C == 1536 && g_ln_fixed) {                                                                            \
+            if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 6, 4>), g4, blk, 0, s, p);                                    \
+            else hipLaunchKernelGGL((layernorm_kernel<XB, 6, 1>), g1, blk, 0, s, p);                                       \
+        } else {                                                                                                           \
+            if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 0, 4>), g4, blk, 0, s, p);                                    \
+            else hipLaunchKernelGGL((layernorm_kernel<XB, 0, 1>), g1, blk, 0, s, p);                                       \
+        }                                                                                                                  \
+    }
+// rows per wave of the row-in-registers kernels: 4 when that still leaves >= 4096 workgroups (two per workgroup slot of
+// the device), otherwise 1 (the DiT's 7 552-row launches need every wave they can get).  g_ln_rows: 0 automatic | 1 | 4.
+static int g_ln_rows = 0;
+static bool g_ln_fixed = true;   // compile-time element counts for C = 1024 / 1536 (0: round 2's run-time count everywhere)
+void ln_set_fixed_count(bool on) { g_ln_fixed = on; }
+void ln_set_rows_per_wave(int rows) { g_ln_rows = rows == 1 || rows == 4 ? rows : 0; }
+static int ln_rows_per_wave(int rows) { return g_ln_rows ? g_ln_rows : (rows >= 4 * 4 * 4096 ? 4 : 1); }
+
 hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;
     if (p.C % 64 || p.C > 2048) return hipErrorInvalidValue;
@@ -490,9 +585,9 @@ hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.y8 && (p.C % 256 || (p.ldy8 & 3) || !p.y_scale)) return hipErrorInvalidValue;
     if (p.x_bf16) {
         if (p.C % 256 || (p.ldx & 3) || (p.ldy & 3) || (p.x_batch_stride & 3)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+        R3G_LN_LAUNCH(true)
     } else if (p.C % 256 == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0) {
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+        R3G_LN_LAUNCH(false)
     } else {
         hipLaunchKernelGGL(layernorm_small_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     }
@@ -569,16 +664,26 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
     return hipGetLastError();
 }
 
+#define R3G_LNDOT_LAUNCH(XB)                                                                                               \
+    {                                                                                                                      \
+        const bool r4 = ln_rows_per_wave(rows) == 4;                                                                       \
+        const dim3 g1((rows + 3) / 4), g4((rows + 15) / 16), blk(256);                                                     \
+        if (C == 1024 && g_ln_fixed) {                                                                                     \
+            if (r4) hipLaunchKernelGGL((ln_dot_kernel<XB, 4, 4>), g4, blk, 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b, out); \
+            else hipLaunchKernelGGL((ln_dot_kernel<XB, 4, 1>), g1, blk, 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b, out);    \
+        } else {                                                                                                           \
+            if (r4) hipLaunchKernelGGL((ln_dot_kernel<XB, 0, 4>), g4, blk, 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b, out); \
+            else hipLaunchKernelGGL((ln_dot_kernel<XB, 0, 1>), g1, blk, 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b, out);    \
+        }                                                                                                                  \
+    }
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb,
                          float eps, const float* w, float b, float* out, hipStream_t s, int x_bf16) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     if (x_bf16) {
         if (C % 256 || C > 2048 || (ldx & 3)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ln_dot_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps,
-                           w, b, out);
+        R3G_LNDOT_LAUNCH(true)
     } else if (C % 256 == 0 && C <= 2048 && (ldx & 3) == 0) {
-        hipLaunchKernelGGL(ln_dot_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w,
-                           b, out);
+        R3G_LNDOT_LAUNCH(false)
     } else {
         hipLaunchKernelGGL(ln_dot_small_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, C, do_ln, lnw, lnb,
                            eps, w, b, out);

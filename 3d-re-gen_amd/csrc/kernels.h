@@ -112,7 +112,9 @@ struct AttnArgs {
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
 // factor the producers of Q fold into it for the current attention kernel: scale * log2(e) (generation 2), or 1
 float attn_q_scale(float scale);
-void attn_set_generation(int gen);   // 2 (default) | 1: the first-round kernel (expects plain Q; same V^T layout)
+void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
+void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave
+void ln_set_fixed_count(bool on);     // 1 (default): compile-time element counts for C = 1024 / 1536
 
 // ------------------------------------------------------------------ elementwise / norms (elem.hip)
 // y(bf16)[r][c] = ((x - mean) * rstd * (w ? w[c] : 1) + (b ? b[c] : 0)) * (1 + scale[batch][c]) + shift[batch][c]

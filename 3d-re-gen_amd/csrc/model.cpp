@@ -1074,6 +1074,8 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
+    else if (!strcmp(name, "ln_rows")) ln_set_rows_per_wave(value);
+    else if (!strcmp(name, "ln_fixed")) ln_set_fixed_count(value != 0);
     else if (!strcmp(name, "mc_rows")) mc_set_rows_per_wave(value);
     else if (!strcmp(name, "mc_deferred")) mc_set_deferred(value != 0);
     else if (!strcmp(name, "lds_dma")) { gemm_set_glds(value != 0); attn_set_glds(value != 0); }

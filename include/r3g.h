@@ -253,7 +253,8 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * (1: 256x256 tiles on the phased counted-vmcnt kernel), "gemm_persistent" (1: its persistent form for bf16 outputs
  * with more tiles than CUs), "gemm_num_cu" (CUs the tile rules assume, default 256), "attn_generation" (7 default: 6 where its
  * 256-query workgroups make four rounds of the device, otherwise 2 | 2 = four waves of 32 queries | 6 = four waves of 64
- * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_pipelined" (0), "attn_ablate"
+ * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
+ * LayerNorm / ln_dot row kernels), "ln_fixed" (1: their instantiations with a compile-time row length for C = 1024 / 1536), "attn_pipelined" (0), "attn_ablate"
  * (timing-only masks, results are garbage), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3

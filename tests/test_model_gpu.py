@@ -320,6 +320,47 @@ def test_full_width_conditioner_vae_and_grid_points(wide):
     assert d <= TOL["grid_logits"]
 
 
+def test_layernorm_instantiations_are_bit_identical(wide):
+    """The row kernels (LayerNorm, ln_dot) exist with a compile-time or a run-time row length and with 1 or 4 rows per
+    wave (options ln_fixed / ln_rows; the automatic choice takes 4 rows only for >= 65 536 rows).  Same element -> lane
+    map, same order of every sum: conditioner (C = 1536), VAE (C = 1024, fp32 rows), geo decoder (bf16 rows, ln_dot, a
+    row count that is not a multiple of 16) and a DiT step (modulated rows) must not change a bit."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(3, 518, 518, generator=g)
+    lat = torch.randn(3072, 64, generator=g)
+    x, _, cond = _inputs(wide, 23)
+    R, start, count = 256, 257 * 257 * 77 + 4321, 3001
+
+    def run():
+        c = wide.gpu.cond_encode(img).clone()
+        z = wide.gpu.vae_decode(lat, return_z=True).clone()
+        out = torch.zeros(257 ** 3, device="cuda")
+        wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+        f = wide.gpu.flow_sample(x[0].clone(), cond, 1, 5.0).clone()
+        return c, z, out[start:start + count].clone(), f
+    outs = []
+    try:
+        for fixed, rows in ((1, 4), (1, 1), (0, 1), (0, 4)):
+            ffi.check(L.r3g_set_option(b"ln_fixed", fixed))
+            ffi.check(L.r3g_set_option(b"ln_rows", rows))
+            outs.append(run())
+    finally:
+        ffi.check(L.r3g_set_option(b"ln_fixed", 1))
+        ffi.check(L.r3g_set_option(b"ln_rows", 0))
+    names = ("conditioner", "vae z", "grid logits", "flow_sample")
+    bad = []
+    for (fixed, rows), o in zip(((1, 1), (0, 1), (0, 4)), outs[1:]):
+        for name, a, b in zip(names, outs[0], o):
+            if not torch.equal(a, b):
+                bad.append("%s: ln_fixed=%d ln_rows=%d differs from (1, 4) in %d elements, max |d| %.3e"
+                           % (name, fixed, rows, int((a != b).sum()), float((a.float() - b.float()).abs().max())))
+    assert not bad, "; ".join(bad)
+    assert all(torch.isfinite(t.float()).all() for t in outs[0])
+
+
 def test_geo_decoder_fp8_mode(wide):
     """option geo_fp8 (BASELINE.json configs[3]): the geo decoder's c_q / MLP GEMMs on e4m3 operands (LayerNorm quantises with
     row scales, the MLP hidden with a static scale) -- grid logits against the fp32 oracle, and against the bf16 path"""
