@@ -1667,7 +1667,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
     return hipGetLastError();
 }
 
-static int g_gemm_waves = 0, g_gemm_stages = 2;  // 0 = automatic tile choice
+static int g_gemm_waves = 0;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 1, g_num_cu = 256;
 bool g_gemm_splitk = false;      // deterministic split-K for deep-K residual GEMMs on under-filled grids (measured: no gain)
@@ -1750,9 +1750,8 @@ void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
-void gemm_set_config(int waves, int stages) {
+void gemm_set_config(int waves) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;
-    if (stages == 2 || stages == 3) g_gemm_stages = stages;
 }
 
 static bool gemm_args_ok(const GemmArgs& p) {

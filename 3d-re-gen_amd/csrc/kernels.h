@@ -76,7 +76,7 @@ void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-sta
 void attn_set_glds(bool on);
 void attn_set_ablate(int mask);   // timing-only ablation builds of the attention kernel (tools/bench_attn.py)
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
-void gemm_set_config(int waves, int stages);
+void gemm_set_config(int waves);   // tile kernel: 0 automatic | 4 | 8 | 9 | 10 | 11 | 12 | 13 | 16 | 32 (include/r3g.h)
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs

@@ -1062,8 +1062,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
-    else if (!strcmp(name, "gemm_waves")) gemm_set_config(value, 0);
-    else if (!strcmp(name, "gemm_stages")) gemm_set_config(0, value);
+    else if (!strcmp(name, "gemm_waves")) gemm_set_config(value);
     else if (!strcmp(name, "gemm_raster")) gemm_set_raster(value);
     else if (!strcmp(name, "gemm_auto_rule")) gemm_set_auto_rule(value, 0);
     else if (!strcmp(name, "gemm_num_cu")) gemm_set_auto_rule(-1, value);

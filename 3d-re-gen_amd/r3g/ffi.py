@@ -98,7 +98,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _LIB = L
-        # ablation switches, e.g. R3G_OPTIONS="gemm_waves=8,gemm_stages=3,fuse_qkv=0"
+        # ablation switches, e.g. R3G_OPTIONS="gemm_waves=8,fuse_qkv=0"
         for item in filter(None, os.environ.get("R3G_OPTIONS", "").split(",")):
             k, v = item.split("=")
             if L.r3g_set_option(k.strip().encode(), int(v)) != 0:

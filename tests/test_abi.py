@@ -98,3 +98,27 @@ def test_library_was_built_from_these_sources():
     spec.loader.exec_module(b)
     assert b.built_digest() is not None, "libr3g.digest missing: run python 3d-re-gen_amd/build.py"
     assert b.built_digest() == b.source_digest(), "libr3g.so is stale: rebuild with python 3d-re-gen_amd/build.py"
+
+
+def test_every_option_is_documented_and_settable():
+    """r3g_set_option's names (csrc/model.cpp) against the list in include/r3g.h: an option nobody can find, or a documented
+    one that the library refuses, is a bug in the boundary.  Setting needs no GPU (plain host state)."""
+    import re
+    src = open(os.path.join(ROOT, "3d-re-gen_amd", "csrc", "model.cpp")).read()
+    hdr = open(os.path.join(ROOT, "include", "r3g.h")).read()
+    body = src[src.index("int r3g_set_option("):]
+    body = body[:body.index("\n}\n")]
+    names = re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', body)
+    assert len(names) >= 20 and len(set(names)) == len(names)
+    doc = hdr[hdr.index("/* A/B switches for tests and ablations."):hdr.index("int r3g_set_option(")]
+    missing = [n for n in names if '"%s"' % n not in doc]
+    assert not missing, "options without documentation in include/r3g.h: %s" % missing
+    from r3g import ffi
+    L = ffi.lib()
+    assert L.r3g_set_option(b"no_such_option", 1) != 0
+    defaults = {"attn_generation": 7, "ln_rows": 0, "ln_fixed": 1, "overlap_mlp": 0, "gemm_waves": 0, "gemm_raster": -1,
+                "gemm_num_cu": 256, "gemm_auto_rule": 1, "mc_rows": 16, "geo_fp8": 0, "gemm_splitk": 0, "attn_pipelined": 0,
+                "attn_ablate": 0}
+    for n in names:
+        v = defaults.get(n, 1)
+        assert L.r3g_set_option(n.encode(), v) == 0, n       # (re)sets the default: the other tests share this process
