@@ -485,11 +485,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
 //  * Q arrives pre-multiplied by scale*log2(e) (the QKV epilogue does it in fp32 before rounding), so a score is
 //    already the exp2 argument;
 //  * lagging maximum: the score accumulators START at -m (the running stabiliser, kept as a 16-register block that is
-//    the C operand of the first QK^T MFMA), so p = exp2(s) with no subtraction and no row maximum on the critical path.
-//    The stabiliser only has to be CLOSE to the maximum: after the exponentials the packed bf16 P registers are reduced
-//    with v_pk_max_u16 (P >= 0: integer order = float order) and a wave-uniform branch fires when some p exceeds 2^6.
-//    Only then is the block's true maximum taken, (O, l) rescaled, and the block's P recomputed from the still-live
-//    scores -- before anything of it entered O or l, so an overflowed p (inf) is never used;
+//    the C operand of the first QK^T MFMA), so p = exp2(s) with no subtraction per score.  The stabiliser only has to be
+//    CLOSE to the maximum: the lane maximum of the 16 shifted scores (8 v_max3) is compared with SCORE_LIMIT and a
+//    wave-uniform branch fires when a VALID query's score exceeds it.  Only then is the block's true maximum taken and
+//    (O, l, the stabiliser block, the scores) moved by it, in place, before the exponentials -- nothing of the block has
+//    entered O or l, an overflowed p is never formed, and no value of the rare path is merged with one of the common path
+//    behind the branch (that merge cost 24 register copies per key block while the test sat behind the exponentials);
+//    rows past Lq hold stale data and take no part in the decision (a valid query's rounding must not depend on them);
 //  * one 32-key score block is live at a time (QK^T -> exp2 -> pack -> PV per block): 16 score registers;
 //  * V^T tiles are read with ds_read_b128: the 8 keys a lane feeds into one PV MFMA are contiguous in the V^T layout
 //    (vt_key_pos in kernels.h: inside every aligned group of 16 keys the two middle 4-key blocks are swapped);
@@ -505,11 +507,6 @@ __device__ __forceinline__ float half_max(float x) {   // max over lanes q and q
 __device__ __forceinline__ float half_sum(float x) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
 }
 
 constexpr float PSUM_LIMIT = 1024.f;   // (pipelined body) a block whose 16 p of one lane sum to more is re-stabilised
