@@ -185,3 +185,32 @@ def test_bench_workload_definition():
         assert 0.25 <= cov <= 0.85, (i, cov)
         rgb = np.asarray(bench.synthetic_crop(i))[..., :3]
         assert (rgb[al == 0] == 255).all()                     # white where transparent
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """the last bench line measured on the MI355X box (profiles/r*_bench.json) against the driver's contract: one JSON object,
+    the named keys with the right types, a roofline and a cpu_baseline object; frac = achieved / peak"""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench.json")))
+    assert files
+    lines = [ln for ln in open(files[-1]).read().split("\n") if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 1e-6       # one object per step on one GPU
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["value"] / c["value"] > 100        # the device path is not the oracle in disguise
