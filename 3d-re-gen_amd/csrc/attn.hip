@@ -15,6 +15,7 @@
 // 4 waves x 32 queries per workgroup share the 64-key K / V^T tiles, double-buffered in LDS through
 // 16-byte LDS-DMA with the bank swizzle on the source chunk index (same scheme as gemm.hip).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -80,6 +81,62 @@ __device__ __forceinline__ void stage_kv(const uint16_t* __restrict__ Kg, const 
     }
 }
 
+// Ragged mode: work entry `e` of the launch, read from the kernarg segment at a uniform offset (scalar loads; indexing the
+// by-value kernel argument with a run-time index would make the compiler copy it to scratch).  Plain mode: entry e is batch e.
+__device__ __forceinline__ int attn_entry_lq(const AttnArgs& p, int e) {
+    typedef const char __attribute__((address_space(4)))* kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const int __attribute__((address_space(4)))*)(ka + offsetof(AttnArgs, ent) + (size_t)e * sizeof(AttnEntry) +
+                                                            offsetof(AttnEntry, lq));
+}
+__device__ __forceinline__ AttnEntry attn_entry(const AttnArgs& p, int e) {
+    AttnEntry r{};
+    if (!p.ragged) {
+        r.lq = p.Lq; r.lk = p.Lk; r.bias_key = -1; r.buf = e;
+        return r;
+    }
+    typedef const char __attribute__((address_space(4)))* kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const AttnEntry __attribute__((address_space(4)))* t =
+        (const AttnEntry __attribute__((address_space(4)))*)(ka + offsetof(AttnArgs, ent) + (size_t)e * sizeof(AttnEntry));
+    r.lq = t->lq; r.lk = t->lk; r.bias_key = t->bias_key; r.bias_log2 = t->bias_log2; r.buf = t->buf;
+    return r;
+}
+// output row of query q of entry e (read at the epilogue only: the three values would otherwise stay live through the key loop)
+__device__ __forceinline__ int64_t attn_entry_out_row(int e, int q) {
+    typedef const char __attribute__((address_space(4)))* kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const AttnEntry __attribute__((address_space(4)))* t =
+        (const AttnEntry __attribute__((address_space(4)))*)(ka + offsetof(AttnArgs, ent) + (size_t)e * sizeof(AttnEntry));
+    const int split = t->o_split;
+    return q < split ? t->o_row0 + q : t->o_row_split + (q - split);
+}
+// (head, entry, query tile) of work item `item`: heads outermost, inside a head entry by entry
+template <int QT>
+__device__ __forceinline__ void attn_work_item(const AttnArgs& p, int item, int& eb, int& hd, int& qt) {
+    if (p.ragged) {
+        int per_head = 0;
+        for (int e = 0; e < p.B; ++e) per_head += (attn_entry_lq(p, e) + QT - 1) / QT;
+        hd = item / per_head;
+        int rem = item - hd * per_head;
+        eb = 0;
+        for (;;) {
+            const int n = (attn_entry_lq(p, eb) + QT - 1) / QT;
+            if (rem < n || eb + 1 >= p.B) break;
+            rem -= n;
+            ++eb;
+        }
+        qt = rem;
+    } else {
+        const int ntq0 = (p.Lq + QT - 1) / QT;
+        const int per_head = ntq0 * p.B;
+        hd = item / per_head;
+        const int rem = item - hd * per_head;
+        eb = rem / ntq0;
+        qt = rem - eb * ntq0;
+    }
+}
+
 // ABL: timing-only ablation mask (tools/bench_attn.py; results are garbage for ABL != 0): 1 no exp2, 2 no row max /
 // rescale, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no LDS-DMA in the loop, 32 no per-tile wait + barrier, 64 no V^T reads
 template <bool GLDS, int ABL = 0>
@@ -87,10 +144,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, hd = blockIdx.y;
+    const int hd = blockIdx.y;
+    const int eb = blockIdx.z;
+    const AttnEntry en = attn_entry(p, eb);
+    const int b = en.buf;
     const int ql = lane & 31, hh = lane >> 5;
     const int q = blockIdx.x * 128 + wid * 32 + ql;
-    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int Lq = en.lq, Lk = en.lk;
     if ((int)blockIdx.x * 128 >= Lq) return;  // ragged: shorter batch entries have fewer query tiles
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
@@ -122,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     }
 
     const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
-    const int bias_key = p.ragged ? p.bias_key[b] : -1;
-    const float bias_raw = p.ragged ? p.bias_log2[b] / sc : 0.f;  // added to the raw (unscaled) score
+    const int bias_key = en.bias_key;
+    const float bias_raw = p.ragged ? en.bias_log2 / sc : 0.f;  // added to the raw (unscaled) score
     stage_kv<GLDS>(Kg, Vtg, p.Lk_pad, 0, smem, wid, lane, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -230,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     // workgroup is issue bound).  The exchange runs for every lane (a padded query's partner is padded too).
     {
         int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
-        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
         uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -297,10 +357,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[5 * TILE_B];  // K ring: 0,1,2 ; V^T ring: 3,4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, hd = blockIdx.y;
+    const int hd = blockIdx.y;
+    const int eb = blockIdx.z;
+    const AttnEntry en = attn_entry(p, eb);
+    const int b = en.buf;
     const int ql = lane & 31, hh = lane >> 5;
     const int q = blockIdx.x * 128 + wid * 32 + ql;
-    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int Lq = en.lq, Lk = en.lk;
     if ((int)blockIdx.x * 128 >= Lq) return;
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
@@ -327,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
     }
     const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
     const bool pad_tail = ntiles * KV_TILE > Lk;
-    const int bias_key = p.ragged ? p.bias_key[b] : -1;
-    const float bias_raw = p.ragged ? p.bias_log2[b] / sc : 0.f;
+    const int bias_key = en.bias_key;
+    const float bias_raw = p.ragged ? en.bias_log2 / sc : 0.f;
 
     auto stage_k = [&](int t, int slot) { stage_half<GLDS>(Kg, 64, (int64_t)t * KV_TILE * 64, 0, smem + slot * TILE_B, wid, lane, tid); };
     auto stage_v = [&](int t, int slot) { stage_half<GLDS>(Vtg, p.Lk_pad, 0, t * KV_TILE, smem + (3 + slot) * TILE_B, wid, lane, tid); };
@@ -463,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_sp(AttnArgs p) {
     const float inv = 1.0f / l_tot;
     if (q < Lq) {
         int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
-        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
         uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -534,27 +597,18 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
     // ---- work item: XCD-aware remap of the 1-D grid, then (head, batch, query tile)
-    int b, hd, qt;
+    int eb, hd, qt;
     {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
         const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
         constexpr int QT = NW * 32;
-        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + QT - 1) / QT;
-        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + QT - 1) / QT : 0) : ntq0;
-        const int per_head = p.ragged ? ntq0 + ntq1 : ntq0 * p.B;
-        hd = item / per_head;
-        int rem = item - hd * per_head;
-        if (p.ragged) {
-            b = rem >= ntq0 ? 1 : 0;
-            qt = rem - (b ? ntq0 : 0);
-        } else {
-            b = rem / ntq0;
-            qt = rem - b * ntq0;
-        }
+        attn_work_item<QT>(p, item, eb, hd, qt);
     }
+    const AttnEntry en = attn_entry(p, eb);
+    const int b = en.buf;
     const int q = qt * (NW * 32) + wid * 32 + ql;
-    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int Lq = en.lq, Lk = en.lk;
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
     const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
@@ -595,8 +649,8 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     }
 
     const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
-    const int bias_key = p.ragged ? p.bias_key[b] : -1;
-    const float bias_l2 = p.ragged ? p.bias_log2[b] : 0.f;
+    const int bias_key = en.bias_key;
+    const float bias_l2 = p.ragged ? en.bias_log2 : 0.f;
     // staging: this lane's two 16-byte chunks of a K tile and of a V^T tile; the per-lane element offsets do not depend on
     // the tile (wave-uniform tile base + constant lane offset: no vector address arithmetic inside the loop)
     constexpr int PPW = 8 / NW;   // 1 KiB pieces (8 tile rows) of each of the two tiles per wave
@@ -869,7 +923,7 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     const float inv = 1.0f / half_sum(l_run);
     {
         int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
-        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
         uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -908,26 +962,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
     constexpr int QT = NW * 64;
-    int b, hd, qt;
+    int eb, hd, qt;
     {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
         const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
-        const int ntq0 = ((p.ragged ? p.lq_b[0] : p.Lq) + QT - 1) / QT;
-        const int ntq1 = p.ragged ? (p.B > 1 ? (p.lq_b[1] + QT - 1) / QT : 0) : ntq0;
-        const int per_head = p.ragged ? ntq0 + ntq1 : ntq0 * p.B;
-        hd = item / per_head;
-        int rem = item - hd * per_head;
-        if (p.ragged) {
-            b = rem >= ntq0 ? 1 : 0;
-            qt = rem - (b ? ntq0 : 0);
-        } else {
-            b = rem / ntq0;
-            qt = rem - b * ntq0;
-        }
+        attn_work_item<QT>(p, item, eb, hd, qt);
     }
+    const AttnEntry en = attn_entry(p, eb);
+    const int b = en.buf;
     const int q0 = qt * QT + wid * 64 + ql;   // query of block 0; block 1 holds query q0 + 32
-    const int Lq = p.ragged ? p.lq_b[b] : p.Lq, Lk = p.ragged ? p.lk_b[b] : p.Lk;
+    const int Lq = en.lq, Lk = en.lk;
     const int kvb = p.kv_batch_stride_zero ? 0 : b;
     const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
     const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
@@ -972,8 +1017,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     }
 
     const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
-    const int bias_key = p.ragged ? p.bias_key[b] : -1;
-    const float bias_l2 = p.ragged ? p.bias_log2[b] : 0.f;
+    const int bias_key = en.bias_key;
+    const float bias_l2 = p.ragged ? en.bias_log2 : 0.f;
     constexpr int PPW = 8 / NW;
     int koff[PPW], voff[PPW];
 #pragma unroll
@@ -1104,7 +1149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
         const int q = q0 + qb * 32;
         const float inv = 1.0f / half_sum(l_run[qb]);
         int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
-        if (p.ragged) orow = (q < p.o_split[b] ? p.o_row0[b] + q : p.o_row_split[b] + (q - p.o_split[b])) * p.ldo;
+        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
         uint16_t* dst = p.O + orow + hd * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -1143,11 +1188,12 @@ float attn_q_scale(float scale) { return g_attn_gen >= 2 ? scale * 1.44269504088
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.ragged) {
-        if (p.B > 2) return hipErrorInvalidValue;
+        if (p.B < 1 || p.B > kAttnMaxEntries) return hipErrorInvalidValue;
         for (int b = 0; b < p.B; ++b) {
-            if (p.lq_b[b] <= 0 || p.lk_b[b] <= 0 || p.lq_b[b] > p.Lq_pad || p.lk_b[b] > p.Lk_pad) return hipErrorInvalidValue;
-            const int nt = (p.lk_b[b] + 63) / 64;
-            if (p.bias_key[b] >= 0 && (p.bias_key[b] < (nt - 1) * 64 || nt * 64 == p.lk_b[b] || p.bias_key[b] >= p.lk_b[b]))
+            const AttnEntry& en = p.ent[b];
+            if (en.lq <= 0 || en.lk <= 0 || en.lq > p.Lq_pad || en.lk > p.Lk_pad || en.buf < 0) return hipErrorInvalidValue;
+            const int nt = (en.lk + 63) / 64;
+            if (en.bias_key >= 0 && (en.bias_key < (nt - 1) * 64 || nt * 64 == en.lk || en.bias_key >= en.lk))
                 return hipErrorInvalidValue;  // the weighted key must sit in the last, padded tile
         }
     }
@@ -1156,7 +1202,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     double pairs = (double)p.B * p.Lq * p.Lk;
     if (p.ragged) {
         pairs = 0;
-        for (int b = 0; b < p.B; ++b) pairs += (double)p.lq_b[b] * p.lk_b[b];
+        for (int b = 0; b < p.B; ++b) pairs += (double)p.ent[b].lq * p.ent[b].lk;
     }
     ProfScope ps(PC_ATTN, 4.0 * p.H * pairs * 64, s);
     if (g_attn_gen >= 2 && !g_attn_pipelined) {
@@ -1164,7 +1210,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         // 6 = 4 waves of 64 queries, 7 = 6 where its 256-query workgroups fill the two slots per CU, otherwise 2
         auto count = [&](int qtile) {
             int n = 0;
-            if (p.ragged) for (int b = 0; b < p.B; ++b) n += (p.lq_b[b] + qtile - 1) / qtile;
+            if (p.ragged) for (int b = 0; b < p.B; ++b) n += (p.ent[b].lq + qtile - 1) / qtile;
             else n = ((p.Lq + qtile - 1) / qtile) * p.B;
             return n * p.H;
         };

@@ -117,6 +117,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         else if (e.layout == QKV_HEAD_KV) { head = g >> 1; type = 1 + (g & 1); }
         else { type = 0; head = g; }
         const int dbase = (lane >> 4) << 2;
+        // row segments: the three from the kernel argument, or (nseg > 3) the three of the device table that can meet this
+        // wave's rows -- the table is sorted and no 128-row window meets more than three (checked at launch)
+        int sg_n = e.nseg, sg_m0[3], sg_m1[3], sg_b[3], sg_d[3];
+#pragma unroll
+        for (int sgi = 0; sgi < 3; ++sgi) { sg_m0[sgi] = e.seg_m0[sgi]; sg_m1[sgi] = e.seg_m1[sgi]; sg_b[sgi] = e.seg_batch[sgi]; sg_d[sgi] = e.seg_dst[sgi]; }
+        if (e.nseg > 3) {
+            // lane i holds segment i (nseg <= 64); the segments that end at or before the wave's first row are counted by a
+            // ballot (the table is sorted), the next three are broadcast from their lanes
+            const int mw_u = __builtin_amdgcn_readfirstlane(m0 + wr * WROWS);
+            const int4* tab = reinterpret_cast<const int4*>(e.seg_tab);
+            int4 t = make_int4(0, 0, 0, 0);
+            if (lane < e.nseg) t = tab[lane];
+            const int first = __popcll(__ballot(lane < e.nseg && t.y <= mw_u));
+            sg_n = 3;
+#pragma unroll
+            for (int sgi = 0; sgi < 3; ++sgi) {
+                const int idx = first + sgi;
+                const bool ok = idx < e.nseg;
+                const int li = ok ? idx : 0;
+                sg_m0[sgi] = ok ? __builtin_amdgcn_readlane(t.x, li) : 0;
+                sg_m1[sgi] = ok ? __builtin_amdgcn_readlane(t.y, li) : 0;
+                sg_b[sgi] = __builtin_amdgcn_readlane(t.z, li);
+                sg_d[sgi] = __builtin_amdgcn_readlane(t.w, li);
+            }
+        }
         const float* nw = type == 0 ? e.qw : e.kw;
         const float* nb = type == 0 ? e.qb : e.kb;
         const bool do_norm = type < 2 && e.norm != QKN_NONE;
@@ -188,14 +213,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (m >= p.M) continue;
             int64_t drow = (int64_t)e.dst_row0 + m;
             int ob = batch;
-            if (e.nseg > 0) {
+            if (sg_n > 0) {
                 bool hit = false;
 #pragma unroll
                 for (int sgi = 0; sgi < 3; ++sgi)
-                    if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
+                    if (sgi < sg_n && m >= sg_m0[sgi] && m < sg_m1[sgi]) {
                         hit = true;
-                        ob = e.seg_batch[sgi];
-                        drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
+                        ob = sg_b[sgi];
+                        drow = (int64_t)sg_d[sgi] + (m - sg_m0[sgi]);
                     }
                 if (!hit) continue;
             }
@@ -227,14 +252,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 ob = batch;
                 drow = (int64_t)e.dst_row0 + m;
                 if (m >= p.M) return false;
-                if (e.nseg == 0) return true;
+                if (sg_n == 0) return true;
                 bool hit = false;
 #pragma unroll
                 for (int sgi = 0; sgi < 3; ++sgi)
-                    if (sgi < e.nseg && m >= e.seg_m0[sgi] && m < e.seg_m1[sgi]) {
+                    if (sgi < sg_n && m >= sg_m0[sgi] && m < sg_m1[sgi]) {
                         hit = true;
-                        ob = e.seg_batch[sgi];
-                        drow = (int64_t)e.seg_dst[sgi] + (m - e.seg_m0[sgi]);
+                        ob = sg_b[sgi];
+                        drow = (int64_t)sg_d[sgi] + (m - sg_m0[sgi]);
                     }
                 return hit;
             };
@@ -1755,6 +1780,17 @@ void gemm_set_config(int waves) {
 }
 
 static bool gemm_args_ok(const GemmArgs& p) {
+    if (p.epi == EPI_QKV && p.qkv.nseg > 3) {
+        if (p.qkv.nseg > 64) return false;
+        // the device table: sorted, disjoint, at most three segments in any window of 128 rows (a wave's rows)
+        const int* t = p.qkv.seg_tab_host;
+        if (!t || !p.qkv.seg_tab) return false;
+        for (int i = 0; i < p.qkv.nseg; ++i) {
+            if (t[4 * i] > t[4 * i + 1]) return false;
+            if (i > 0 && t[4 * i] < t[4 * (i - 1) + 1]) return false;
+            if (i >= 3 && t[4 * i] - t[4 * (i - 3) + 1] + 1 < 128) return false;
+        }
+    }
     return !(p.K % 64 != 0 || p.K <= 0 || (p.N & 3) || (p.lda & 7) || (p.ldw & 7) || (p.epi == EPI_QKV && p.N % 64));
 }
 

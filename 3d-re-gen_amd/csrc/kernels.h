@@ -48,6 +48,12 @@ struct QkvEpi {
     // row seg_dst + (m - seg_m0); rows in no segment are dropped.  nseg == 0: batch = GEMM batch, row = dst_row0 + m.
     int nseg;
     int seg_m0[3], seg_m1[3], seg_batch[3], seg_dst[3];
+    // nseg > 3: the segments live in device memory instead, seg_tab[i] = {m0, m1, batch, dst} as four ints, sorted by m0,
+    // disjoint, and such that no window of 128 consecutive rows meets more than three of them (gemm_launch checks the host
+    // copy seg_tab_host): a wave picks the three that can meet its rows and proceeds as above.  (Several objects' CFG
+    // pairs in one DiT launch: 4 segments per object.)
+    const int* seg_tab;
+    const int* seg_tab_host;
 };
 
 struct GemmArgs {
@@ -85,6 +91,14 @@ void gemm_set_phased(bool on);   // 256x256 tiles: phased kernel (default) or th
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
+constexpr int kAttnMaxEntries = 8;
+struct AttnEntry {
+    int lq, lk;
+    int o_split, bias_key;
+    int64_t o_row0, o_row_split;
+    float bias_log2;
+    int buf;
+};
 struct AttnArgs {
     const uint16_t* Q;   // bf16 [B][H][Lq_pad][64]
     const uint16_t* K;   // bf16 [B][H][Lk_pad][64]
@@ -97,16 +111,14 @@ struct AttnArgs {
     int kv_batch_stride_zero;  // 1: K/V are shared by all batches (cross attention with B query chunks)
     float scale;         // softmax scale (1/sqrt(64))
     int q_prescaled;     // 1: Q already holds q * scale * log2(e) (QkvEpi::q_scale = attn_q_scale())
-    // Ragged mode (B <= 2; CFG with a de-duplicated unconditional context): per-batch lengths, an output row map
-    //   row(b, q) = q < o_split[b] ? o_row0[b] + q : o_row_split[b] + (q - o_split[b])     (strideO ignored)
-    // and one key per batch that stands for `2^bias_log2[b]` identical keys (its score gets +bias_log2 in log2 units;
-    // the key must lie in the last, padded key tile).  bias_key < 0: none.
+    // Ragged mode (B <= kAttnMaxEntries work entries; CFG with a de-duplicated unconditional context, for one or several
+    // objects): entry e has its own lengths, reads Q / K / V^T of batch slot ent[e].buf, an output row map
+    //   row(e, q) = q < o_split ? o_row0 + q : o_row_split + (q - o_split)     (strideO ignored)
+    // and one key that stands for `2^bias_log2` identical keys (its score gets +bias_log2 in log2 units; the key must lie
+    // in the last, padded key tile).  bias_key < 0: none.  Work items are issued entry by entry inside a head: list
+    // the long entries first.
     int ragged;
-    int lq_b[2], lk_b[2];
-    int64_t o_row0[2], o_row_split[2];
-    int o_split[2];
-    int bias_key[2];
-    float bias_log2[2];
+    AttnEntry ent[kAttnMaxEntries];
 };
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s);

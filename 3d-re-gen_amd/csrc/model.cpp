@@ -55,6 +55,7 @@ static int g_geo_fp8 = 0;   // BASELINE.json configs[3]: geo decoder GEMMs on fp
 constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP hidden: |GELU| up to 28 representable
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
+static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
 
 struct Model {
     r3g_model_config c{};
@@ -92,6 +93,16 @@ struct Model {
     struct W8 { uint8_t* w8; float* sw; };
     std::unordered_map<const void*, W8> w8;
     float *fp8_sa = nullptr, *fp8_sconst = nullptr;
+    // activation arena of the CFG-de-duplicated DiT for `cap` objects per launch (allocated on first use), and the segment
+    // tables of its fused QKV epilogues for `nb` objects
+    struct DitBatch {
+        int cap = 0, nb = 0;
+        char* base = nullptr;
+        float *f32a = nullptr, *v2 = nullptr;
+        uint16_t *xn = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *cat = nullptr, *inb = nullptr, *ctx = nullptr;
+        int *seg_txt = nullptr, *seg_all = nullptr;
+        std::vector<int> h_seg_txt, h_seg_all;
+    } db;
     std::string err;
 
     const Tensor* find(const std::string& name) const {
@@ -381,34 +392,85 @@ static int dit_forward(Model& m, const float* x_in, const float* t_dev, float t_
     return R3G_OK;
 }
 
-// ---- DiT under classifier-free guidance with a de-duplicated unconditional context -------------------------
+// ---- DiT under classifier-free guidance with a de-duplicated unconditional context, for NB objects at once -------------
 // The unconditional context is `zeros_like(cond)` (upstream conditioner.unconditional_embedding): after cond_in its
 // Lc tokens are identical, and every layer keeps them identical (same input, same per-token ops, same attention
 // row).  They are therefore carried as ONE token whose key counts Lc times in the softmax (score + log2(Lc) in the
 // log2 domain) -- exactly the same function, 3073 instead of 4442 tokens for that batch entry.
-// Global row layout of all row-indexed buffers (both CFG entries share timestep, hence modulation and gates):
-//   [0, Nl) latent(cond) | [Nl, Nl+Lc) cond tokens | row T = Nl+Lc: the unconditional context token | pad |
-//   [R1, R1+Nl) latent(uncond),  R1 = roundup(T+1, 128).   txt-stream GEMMs see Lc+1 contiguous rows.
-static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, const uint16_t* cond, const uint16_t* uncond_row,
-                                 float* out2, hipStream_t s) {
+// Objects are independent and share the timestep (hence modulation and gates), so NB of them go through every layer in ONE
+// launch (upstream: the pipeline's batch dimension when `image` is a list; the reference's object-level parallelism is the
+// pool at src/2d_to_3d_models/run.py:176-193).  A GEMM row does not know which object it belongs to: per-object results are
+// bit-identical to NB = 1.  Global row layout of all row-indexed buffers (CFG entry e = 2*object + {0 cond, 1 uncond}):
+//   [e*Nl, (e+1)*Nl)  latent rows of entry e          (2*NB blocks; the img stream of the double blocks)
+//   TX0 = 2*NB*Nl;  [TX0 + o*Ltp, +Lc) cond tokens of object o | row TX0 + o*Ltp + Lc: its unconditional token | pad to Ltp
+// (Ltp = dit_txt_rows(): Lc + 1 rounded up to whole 16-token groups of V^T, at least 128).  The txt-stream GEMMs see NB*Ltp contiguous rows, the
+// single blocks all Rall = TX0 + NB*Ltp rows.
+static constexpr int kMaxObjects = kAttnMaxEntries / 2;
+// rows per object in the txt block: Lc cond tokens + 1 unconditional token, padded so that 16-token groups of V^T stay whole
+// and (>= 128) no 128-row window of a GEMM meets more than three row segments (QkvEpi::seg_tab)
+static int dit_txt_rows(const Model& m) { return (int)std::max<int64_t>(128, rup(m.Lc + 1, 16)); }
+
+static int ensure_dit_batch(Model& m, int NB) {
+    Model::DitBatch& d = m.db;
     const r3g_model_config& c = m.c;
+    const int H = m.H, Nl = c.vae_num_latents, Lc = m.Lc;
+    const int Ltp = dit_txt_rows(m);
+    if (d.cap < NB) {
+        if (d.base) { R3G_TRY(hipDeviceSynchronize()); (void)hipFree(d.base); d.base = nullptr; d.cap = 0; }
+        const int64_t rows = rup(2LL * NB * Nl + (int64_t)NB * Ltp, 256);
+        const int64_t n_attn = 2LL * NB * m.Hd * m.Tpad * 64;
+        size_t off = 0;
+        auto carve = [&](int64_t bytes) { size_t o = off; off += (size_t)rup(bytes, 256); return o; };
+        const size_t o_f = carve(rows * H * 4), o_xn = carve(rows * H * 2), o_q = carve(n_attn * 2), o_k = carve(n_attn * 2),
+                     o_v = carve(n_attn * 2), o_cat = carve(rows * 5 * H * 2), o_inb = carve((int64_t)NB * Nl * m.cin_pad * 2),
+                     o_ctx = carve((int64_t)NB * Ltp * c.dit_context_dim * 2), o_v2 = carve(2LL * NB * Nl * c.dit_in_channels * 4),
+                     o_seg = carve(2 * 64 * 16);
+        R3G_TRY(hipMalloc((void**)&d.base, off));
+        R3G_TRY(hipMemset(d.base, 0, off));   // padded rows / columns must start finite
+        char* a = d.base;
+        d.f32a = (float*)(a + o_f); d.xn = (uint16_t*)(a + o_xn); d.Q = (uint16_t*)(a + o_q); d.K = (uint16_t*)(a + o_k);
+        d.Vt = (uint16_t*)(a + o_v); d.cat = (uint16_t*)(a + o_cat); d.inb = (uint16_t*)(a + o_inb);
+        d.ctx = (uint16_t*)(a + o_ctx); d.v2 = (float*)(a + o_v2); d.seg_txt = (int*)(a + o_seg); d.seg_all = d.seg_txt + 64 * 4;
+        d.cap = NB;
+        d.nb = 0;
+    }
+    if (d.nb != NB) {
+        // segment tables of the EPI_QKV epilogue: {first row, end row, attention batch slot, destination row}
+        const int TX0 = 2 * NB * Nl;
+        d.h_seg_txt.clear(); d.h_seg_all.clear();
+        for (int e = 0; e < 2 * NB; ++e) { const int v[4] = {e * Nl, (e + 1) * Nl, e, 0}; d.h_seg_all.insert(d.h_seg_all.end(), v, v + 4); }
+        for (int o = 0; o < NB; ++o) {
+            const int c0[4] = {o * Ltp, o * Ltp + Lc, 2 * o, Nl}, u0[4] = {o * Ltp + Lc, o * Ltp + Lc + 1, 2 * o + 1, Nl};
+            d.h_seg_txt.insert(d.h_seg_txt.end(), c0, c0 + 4); d.h_seg_txt.insert(d.h_seg_txt.end(), u0, u0 + 4);
+            const int c1[4] = {TX0 + c0[0], TX0 + c0[1], c0[2], c0[3]}, u1[4] = {TX0 + u0[0], TX0 + u0[1], u0[2], u0[3]};
+            d.h_seg_all.insert(d.h_seg_all.end(), c1, c1 + 4); d.h_seg_all.insert(d.h_seg_all.end(), u1, u1 + 4);
+        }
+        R3G_TRY(hipDeviceSynchronize());   // a previous launch may still read the tables
+        R3G_TRY(hipMemcpy(d.seg_txt, d.h_seg_txt.data(), d.h_seg_txt.size() * 4, hipMemcpyHostToDevice));
+        R3G_TRY(hipMemcpy(d.seg_all, d.h_seg_all.data(), d.h_seg_all.size() * 4, hipMemcpyHostToDevice));
+        d.nb = NB;
+    }
+    return R3G_OK;
+}
+
+// x_lat f32 [NB][Nl][Cin]; the context rows (m.db.ctx) are filled by the caller; out2 f32 [2*NB][Nl][Cin] (entry order)
+static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, float* out2, int NB, hipStream_t s) {
+    const r3g_model_config& c = m.c;
+    Model::DitBatch& d = m.db;
     const int H = m.H, Nl = c.vae_num_latents, Lc = m.Lc, T = m.T, Tpad = m.Tpad, heads = m.Hd;
-    const int R1 = (int)rup(T + 1, 128), Rtot = R1 + Nl, Ltxt = Lc + 1;
-    if (Rtot > 2 * Tpad) return fail(R3G_ERR_INVALID, "dedup layout does not fit the activation arena");
-    const int64_t latS = (int64_t)R1 * H;  // row stride between the two latent blocks
-    const int64_t catld = 5 * (int64_t)H, qkvld = 3 * (int64_t)H;
+    const int Ltp = dit_txt_rows(m), TX0 = 2 * NB * Nl, Mtxt = NB * Ltp, Rall = TX0 + Mtxt;
+    const int64_t catld = 5 * (int64_t)H;
     const int mh = c.dit_mlp_hidden;
+    if (d.nb != NB) return fail(R3G_ERR_STATE, "dit batch arena not prepared for %d objects", NB);
     Lin l;
-    // inputs: the same latents for both entries; cond rows + the single unconditional row
-    R3G_TRY(cast_pad_launch(x_lat, c.dit_in_channels, m.inb, m.cin_pad, Nl, c.dit_in_channels, m.cin_pad, 1.0f, s));
+    // inputs: every object's latents feed both of its CFG entries; cond rows + the single unconditional row per object
+    R3G_TRY(cast_pad_launch(x_lat, c.dit_in_channels, d.inb, m.cin_pad, NB * Nl, c.dit_in_channels, m.cin_pad, 1.0f, s));
     R3G_RC(get_lin(m, "model.latent_in", true, &l));
-    R3G_RC(gemm(m.inb, m.cin_pad, 0, l, 0, H, m.f32a, H, latS, Nl, m.cin_pad, EPI_F32, nullptr, 0, 2, s));
-    uint16_t* ctx_rows = m.qkv;  // scratch: [Lc+1][context_dim] bf16
-    R3G_TRY(hipMemcpyAsync(ctx_rows, cond, (size_t)Lc * c.dit_context_dim * 2, hipMemcpyDeviceToDevice, s));
-    R3G_TRY(hipMemcpyAsync(ctx_rows + (int64_t)Lc * c.dit_context_dim, uncond_row, (size_t)c.dit_context_dim * 2,
-                           hipMemcpyDeviceToDevice, s));
+    for (int j = 0; j < 2; ++j)
+        R3G_RC(gemm(d.inb, m.cin_pad, (int64_t)Nl * m.cin_pad, l, 0, H, d.f32a + (int64_t)j * Nl * H, H, 2LL * Nl * H, Nl, m.cin_pad,
+                    EPI_F32, nullptr, 0, NB, s));
     R3G_RC(get_lin(m, "model.cond_in", true, &l));
-    R3G_RC(gemm(ctx_rows, c.dit_context_dim, 0, l, 0, H, m.f32a + (int64_t)Nl * H, H, 0, Ltxt, c.dit_context_dim, EPI_F32,
+    R3G_RC(gemm(d.ctx, c.dit_context_dim, 0, l, 0, H, d.f32a + (int64_t)TX0 * H, H, 0, Mtxt, c.dit_context_dim, EPI_F32,
                 nullptr, 0, 1, s));
     R3G_TRY(timestep_embedding_launch(nullptr, t_scalar, 1, c.dit_time_factor, m.temb, s));
     R3G_RC(get_lin(m, "model.time_in.in_layer", true, &l));
@@ -419,60 +481,64 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
     R3G_TRY(gemv_multi_launch(m.vec, 1, H, m.mod_jobs, m.n_mod_jobs, m.mod_all, 1, s));
 
     AttnArgs at{};
-    at.Q = m.Q; at.K = m.K; at.Vt = m.Vt; at.O = m.cat; at.ldo = catld; at.strideO = 0;
-    at.B = 2; at.H = heads; at.Lq = T; at.Lq_pad = Tpad; at.Lk = T; at.Lk_pad = Tpad; at.scale = 0.125f;
+    at.Q = d.Q; at.K = d.K; at.Vt = d.Vt; at.O = d.cat; at.ldo = catld; at.strideO = 0;
+    at.B = 2 * NB; at.H = heads; at.Lq = T; at.Lq_pad = Tpad; at.Lk = T; at.Lk_pad = Tpad; at.scale = 0.125f;
     at.q_prescaled = attn_q_scale(0.125f) != 1.0f;
     at.ragged = 1;
-    at.lq_b[0] = T; at.lk_b[0] = T; at.lq_b[1] = Nl + 1; at.lk_b[1] = Nl + 1;
-    at.o_row0[0] = 0; at.o_split[0] = T; at.o_row_split[0] = 0;
-    at.o_row0[1] = R1; at.o_split[1] = Nl; at.o_row_split[1] = T;
-    at.bias_key[0] = -1; at.bias_log2[0] = 0.f;
-    at.bias_key[1] = Nl; at.bias_log2[1] = log2f((float)Lc);
+    for (int o = 0; o < NB; ++o) {   // work order: the long (conditional) entries first
+        AttnEntry& ec = at.ent[o];
+        ec.lq = T; ec.lk = T; ec.buf = 2 * o; ec.o_row0 = (int64_t)(2 * o) * Nl; ec.o_split = Nl;
+        ec.o_row_split = (int64_t)TX0 + (int64_t)o * Ltp; ec.bias_key = -1; ec.bias_log2 = 0.f;
+        AttnEntry& eu = at.ent[NB + o];
+        eu.lq = Nl + 1; eu.lk = Nl + 1; eu.buf = 2 * o + 1; eu.o_row0 = (int64_t)(2 * o + 1) * Nl; eu.o_split = Nl;
+        eu.o_row_split = (int64_t)TX0 + (int64_t)o * Ltp + Lc; eu.bias_key = Nl; eu.bias_log2 = log2f((float)Lc);
+    }
 
     auto qkv_args = [&](const std::string& qn, const std::string& kn, QkvSplitArgs* q) -> int {
         *q = QkvSplitArgs{};
         q->q_off = 0; q->k_off = H; q->v_off = 2 * H; q->head_stride = 64;
-        q->Q = m.Q; q->K = m.K; q->Vt = m.Vt; q->Lq_pad = Tpad; q->Lk_pad = Tpad;
+        q->Q = d.Q; q->K = d.K; q->Vt = d.Vt; q->Lq_pad = Tpad; q->Lk_pad = Tpad;
         q->H = heads; q->norm = QKN_RMS; q->eps = 1e-6f; q->q_scale = attn_q_scale(0.125f);
         R3G_RC(get_vec(m, qn, 64, &q->qw));
         R3G_RC(get_vec(m, kn, 64, &q->kw));
         return R3G_OK;
     };
+    // nseg == 0: attention batch slot = GEMM batch index, destination row = GEMM row
     auto qkv_gemm_args = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, const QkvSplitArgs& q, int nseg,
-                             const int (*seg)[4]) {
+                             const int* seg_dev, const std::vector<int>* seg_host) {
         GemmArgs p{};
         p.A = A; p.lda = H; p.strideA = strideA; p.W = lin.w; p.ldw = lin.ldw; p.bias = lin.b;
         p.M = M; p.N = 3 * H; p.K = H; p.epi = EPI_QKV;
         p.qkv.Q = q.Q; p.qkv.K = q.K; p.qkv.Vt = q.Vt; p.qkv.Lq_pad = q.Lq_pad; p.qkv.Lk_pad = q.Lk_pad;
         p.qkv.dst_row0 = 0; p.qkv.heads = heads; p.qkv.layout = QKV_KHD; p.qkv.norm = q.norm;
         p.qkv.qw = q.qw; p.qkv.kw = q.kw; p.qkv.eps = q.eps; p.qkv.q_scale = q.q_scale; p.qkv.nseg = nseg;
-        for (int i = 0; i < nseg; ++i) {
-            p.qkv.seg_m0[i] = seg[i][0]; p.qkv.seg_m1[i] = seg[i][1]; p.qkv.seg_batch[i] = seg[i][2]; p.qkv.seg_dst[i] = seg[i][3];
+        if (nseg > 3) {
+            p.qkv.seg_tab = seg_dev; p.qkv.seg_tab_host = seg_host->data();
+        } else {
+            for (int i = 0; i < nseg; ++i) {
+                p.qkv.seg_m0[i] = (*seg_host)[4 * i]; p.qkv.seg_m1[i] = (*seg_host)[4 * i + 1];
+                p.qkv.seg_batch[i] = (*seg_host)[4 * i + 2]; p.qkv.seg_dst[i] = (*seg_host)[4 * i + 3];
+            }
         }
         return p;
     };
-    auto launch_qkv = [&](const uint16_t* A, int64_t strideA, const Lin& lin, int M, int batch, const QkvSplitArgs& q, int nseg,
-                          const int (*seg)[4]) -> int {
-        hipError_t e = gemm_launch(qkv_gemm_args(A, strideA, lin, M, q, nseg, seg), batch, s);
-        if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv dedup)");
-        return R3G_OK;
-    };
 
-    // LayerNorm + modulation of both streams: one launch over all rows [0, Rtot) (the txt rows take their own
-    // scale / shift; the pad rows between the blocks are normalised too and never read), or one launch per stream
+    float* xt = d.f32a + (int64_t)TX0 * H;
+    uint16_t* xnt = d.xn + (int64_t)TX0 * H;
+    uint16_t* catt = d.cat + (int64_t)TX0 * catld;
+    // LayerNorm + modulation of both streams: one launch over all rows (the txt rows take their own scale / shift; pad
+    // rows are normalised too and never read), or one launch per stream
     auto ln_streams = [&](const float* sc_i, const float* sh_i, const float* sc_t, const float* sh_t) -> int {
-        float* xt_ = m.f32a + (int64_t)Nl * H;
-        uint16_t* xnt_ = m.xn + (int64_t)Nl * H;
         if (!g_group_streams) {
-            R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, sc_i, sh_i, 0, 1e-6f, s));
-            return layernorm(xt_, H, 0, xnt_, H, 0, Ltxt, 1, H, nullptr, nullptr, sc_t, sh_t, 0, 1e-6f, s);
+            R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, sc_i, sh_i, 0, 1e-6f, s));
+            return layernorm(xt, H, 0, xnt, H, 0, Mtxt, 1, H, nullptr, nullptr, sc_t, sh_t, 0, 1e-6f, s);
         }
         LnArgs p{};
-        p.x = m.f32a; p.ldx = H; p.x_batch_stride = 0;
-        p.y = m.xn; p.ldy = H; p.y_batch_stride = 0;
+        p.x = d.f32a; p.ldx = H; p.x_batch_stride = 0;
+        p.y = d.xn; p.ldy = H; p.y_batch_stride = 0;
         p.scale = sc_i; p.shift = sh_i; p.mod_stride = 0;
-        p.seg2_row0 = Nl; p.seg2_row1 = Nl + Ltxt; p.scale2 = sc_t; p.shift2 = sh_t;
-        p.rows = Rtot; p.C = H; p.rows_per_batch = Rtot; p.eps = 1e-6f;
+        p.seg2_row0 = TX0; p.seg2_row1 = Rall; p.scale2 = sc_t; p.shift2 = sh_t;
+        p.rows = Rall; p.C = H; p.rows_per_batch = Rall; p.eps = 1e-6f;
         hipError_t e = layernorm_launch(p, s);
         if (e != hipSuccess) return hip_fail(e, "layernorm_launch(streams)");
         return R3G_OK;
@@ -483,43 +549,38 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
         const float* mt = m.mod_all + m.mod_off[2 * i + 1];
         QkvSplitArgs qi, qt;
         Lin li, lt;
-        // img stream: two latent blocks (batch 2, stride R1 rows); txt stream: Lc cond tokens (entry 0) + 1
-        // unconditional token (entry 1).  Each layer of the two streams is one grouped launch.
-        float* xt = m.f32a + (int64_t)Nl * H;
-        uint16_t* xnt = m.xn + (int64_t)Nl * H;
-        uint16_t* catt = m.cat + (int64_t)Nl * catld;
-        const int64_t catS = (int64_t)R1 * catld;
+        // img stream: the 2*NB latent blocks (one GEMM batch entry = one attention batch slot); txt stream: per object Lc
+        // cond tokens (slot 2o) + 1 unconditional token (slot 2o+1).  Each layer of the two streams is one grouped launch.
         R3G_RC(ln_streams(mi + H, mi, mt + H, mt));
         R3G_RC(get_lin(m, bi + "_attn.qkv", c.dit_qkv_bias != 0, &li));
         R3G_RC(get_lin(m, bt + "_attn.qkv", c.dit_qkv_bias != 0, &lt));
         R3G_RC(qkv_args(bi + "_attn.norm.query_norm.scale", bi + "_attn.norm.key_norm.scale", &qi));
         R3G_RC(qkv_args(bt + "_attn.norm.query_norm.scale", bt + "_attn.norm.key_norm.scale", &qt));
-        const int seg_t[2][4] = {{0, Lc, 0, Nl}, {Lc, Lc + 1, 1, Nl}};
-        R3G_RC(gemm_pair(qkv_gemm_args(m.xn, latS, li, Nl, qi, 0, nullptr), 2, qkv_gemm_args(xnt, 0, lt, Ltxt, qt, 2, seg_t), 1, s));
+        R3G_RC(gemm_pair(qkv_gemm_args(d.xn, (int64_t)Nl * H, li, Nl, qi, 0, nullptr, nullptr), 2 * NB,
+                         qkv_gemm_args(xnt, 0, lt, Mtxt, qt, 2 * NB, d.seg_txt, &d.h_seg_txt), 1, s));
         hipError_t e = attention_launch(at, s);
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
         // attention projection
         R3G_RC(get_lin(m, bi + "_attn.proj", true, &li));
         R3G_RC(get_lin(m, bt + "_attn.proj", true, &lt));
-        R3G_RC(gemm_pair(gemm_args(m.cat, catld, catS, li, 0, H, m.f32a, H, latS, Nl, H, EPI_RESID_F32, mi + 2 * H, 0), 2,
-                         gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Ltxt, H, EPI_RESID_F32, mt + 2 * H, 0), 1, s));
+        R3G_RC(gemm_pair(gemm_args(d.cat, catld, 0, li, 0, H, d.f32a, H, 0, TX0, H, EPI_RESID_F32, mi + 2 * H, 0), 1,
+                         gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Mtxt, H, EPI_RESID_F32, mt + 2 * H, 0), 1, s));
         // MLP
         R3G_RC(ln_streams(mi + 4 * H, mi + 3 * H, mt + 4 * H, mt + 3 * H));
         R3G_RC(get_lin(m, bi + "_mlp.0", true, &li));
         R3G_RC(get_lin(m, bt + "_mlp.0", true, &lt));
-        R3G_RC(gemm_pair(gemm_args(m.xn, H, latS, li, 0, mh, m.cat + H, catld, catS, Nl, H, EPI_BF16_GELU_TANH, nullptr, 0), 2,
-                         gemm_args(xnt, H, 0, lt, 0, mh, catt + H, catld, 0, Ltxt, H, EPI_BF16_GELU_TANH, nullptr, 0), 1, s));
+        R3G_RC(gemm_pair(gemm_args(d.xn, H, 0, li, 0, mh, d.cat + H, catld, 0, TX0, H, EPI_BF16_GELU_TANH, nullptr, 0), 1,
+                         gemm_args(xnt, H, 0, lt, 0, mh, catt + H, catld, 0, Mtxt, H, EPI_BF16_GELU_TANH, nullptr, 0), 1, s));
         R3G_RC(get_lin(m, bi + "_mlp.2", true, &li));
         R3G_RC(get_lin(m, bt + "_mlp.2", true, &lt));
-        R3G_RC(gemm_pair(gemm_args(m.cat + H, catld, catS, li, 0, H, m.f32a, H, latS, Nl, mh, EPI_RESID_F32, mi + 5 * H, 0), 2,
-                         gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Ltxt, mh, EPI_RESID_F32, mt + 5 * H, 0), 1, s));
+        R3G_RC(gemm_pair(gemm_args(d.cat + H, catld, 0, li, 0, H, d.f32a, H, 0, TX0, mh, EPI_RESID_F32, mi + 5 * H, 0), 1,
+                         gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Mtxt, mh, EPI_RESID_F32, mt + 5 * H, 0), 1, s));
     }
-    const int seg_s[3][4] = {{0, T, 0, 0}, {T, T + 1, 1, Nl}, {R1, R1 + Nl, 1, 0}};
-    // Single blocks: linear1 = [qkv | mlp-in].  The attention grid (960 workgroups of unequal length on 768 slots)
-    // leaves a fifth of the machine idle in its second dispatch round; the MLP half of linear1 does not depend on the
-    // attention, so it CAN be issued on a second stream (fork after the LayerNorm, join before linear2; option
-    // overlap_mlp).  Same kernels, same operands: the result does not change.  It paid (-1.1 %) while that GEMM ran
-    // 64 KiB workgroups that fit beside attention workgroups; the persistent 256x256 kernel owns a whole CU's LDS.
+    // Single blocks: linear1 = [qkv | mlp-in] over all rows.  The attention grid leaves part of the machine idle in its
+    // last dispatch round; the MLP half of linear1 does not depend on the attention, so it CAN be issued on a second stream
+    // (fork after the LayerNorm, join before linear2; option overlap_mlp).  Same kernels, same operands: the result does not
+    // change.  It paid (-1.1 %) while that GEMM ran 64 KiB workgroups that fit beside attention workgroups; the persistent
+    // 256x256 kernel owns a whole CU's LDS.
     const bool overlap = g_overlap_mlp && c.dit_depth_single > 0;
     if (overlap && !m.aux) {
         R3G_TRY(hipStreamCreateWithFlags(&m.aux, hipStreamNonBlocking));
@@ -529,35 +590,39 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, c
     for (int i = 0; i < c.dit_depth_single; ++i) {
         const std::string blk = fmt("model.single_blocks.%d", i);
         const float* mm = m.mod_all + m.mod_off[2 * c.dit_depth_double + i];
-        R3G_RC(layernorm(m.f32a, H, 0, m.xn, H, 0, Rtot, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s));
+        R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, Rall, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s));
         R3G_RC(get_lin(m, blk + ".linear1", true, &l));
         QkvSplitArgs q;
         R3G_RC(qkv_args(blk + ".norm.query_norm.scale", blk + ".norm.key_norm.scale", &q));
+        const GemmArgs pq = qkv_gemm_args(d.xn, 0, l, Rall, q, 4 * NB, d.seg_all, &d.h_seg_all);
+        auto launch_qkv = [&]() -> int {
+            hipError_t e = gemm_launch(pq, 1, s);
+            if (e != hipSuccess) return hip_fail(e, "gemm_launch(qkv dedup)");
+            return R3G_OK;
+        };
         hipStream_t sm = s;
         if (overlap) {   // fork after the QKV projection: the MLP-in GEMM starts together with the attention kernel
-            R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+            R3G_RC(launch_qkv());
             R3G_TRY(hipEventRecord(m.ev_fork, s));
             R3G_TRY(hipStreamWaitEvent(m.aux, m.ev_fork, 0));
             sm = m.aux;
         }
-        R3G_RC(gemm(m.xn, H, 0, l, 3 * H, mh, m.cat + H, catld, 0, Rtot, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, sm));
+        R3G_RC(gemm(d.xn, H, 0, l, 3 * H, mh, d.cat + H, catld, 0, Rall, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, sm));
         if (overlap) {
             R3G_TRY(hipEventRecord(m.ev_join, m.aux));
         } else {
-            R3G_RC(launch_qkv(m.xn, 0, l, Rtot, 1, q, 3, seg_s));
+            R3G_RC(launch_qkv());
         }
         hipError_t e = attention_launch(at, s);
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
         if (overlap) R3G_TRY(hipStreamWaitEvent(s, m.ev_join, 0));
         R3G_RC(get_lin(m, blk + ".linear2", true, &l));
-        R3G_RC(gemm(m.cat, catld, 0, l, 0, H, m.f32a, H, 0, Rtot, H + mh, EPI_RESID_F32, mm + 2 * H, 0, 1, s));
+        R3G_RC(gemm(d.cat, catld, 0, l, 0, H, d.f32a, H, 0, Rall, H + mh, EPI_RESID_F32, mm + 2 * H, 0, 1, s));
     }
     const float* fm = m.mod_all + m.mod_off[2 * c.dit_depth_double + c.dit_depth_single];
-    R3G_RC(layernorm(m.f32a, H, latS, m.xn, H, latS, Nl, 2, H, nullptr, nullptr, fm + H, fm, 0, 1e-6f, s));
+    R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, fm + H, fm, 0, 1e-6f, s));
     R3G_RC(get_lin(m, "model.final_layer.linear", true, &l));
-    R3G_RC(gemm(m.xn, H, latS, l, 0, c.dit_in_channels, out2, c.dit_in_channels, (int64_t)Nl * c.dit_in_channels, Nl, H, EPI_F32,
-                nullptr, 0, 2, s));
-    (void)qkvld;
+    R3G_RC(gemm(d.xn, H, 0, l, 0, c.dit_in_channels, out2, c.dit_in_channels, 0, TX0, H, EPI_F32, nullptr, 0, 1, s));
     return R3G_OK;
 }
 
@@ -820,6 +885,7 @@ static void model_free(Model* m) {
     }
     if (m->fp8_sa) (void)hipFree(m->fp8_sa);
     if (m->fp8_sconst) (void)hipFree(m->fp8_sconst);
+    if (m->db.base) (void)hipFree(m->db.base);
     delete m;
 }
 
@@ -942,12 +1008,13 @@ int r3g_dit_stream(r3g_ctx* ctx, float* d_out, int batch, void* stream) {
     return R3G_OK;
 }
 
-int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
-                    float shift, int uncond_uniform, void* stream) {
-    NEED_MODEL("r3g_flow_sample");
-    if (!d_latents || !d_cond2 || steps < 1) return fail(R3G_ERR_INVALID, "r3g_flow_sample: bad argument");
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n = (int64_t)m->c.vae_num_latents * m->c.dit_in_channels;
+// The denoising loop for n_objects objects (latents f32 [n][Nl][Cin], cond2 bf16 [n][2][Lc][D]).  With a de-duplicated
+// unconditional context all objects go through every DiT layer together; otherwise one after the other.
+static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int n_objects, int steps, float guidance_scale,
+                       float shift, int uncond_uniform, hipStream_t s) {
+    const r3g_model_config& c = m->c;
+    const int64_t n = (int64_t)c.vae_num_latents * c.dit_in_channels;
+    const int64_t cond_elems = (int64_t)m->Lc * c.dit_context_dim;
     // sigmas = linspace(0,1,steps) (shifted), + a trailing 1: the last update has d_sigma = 0, as upstream
     std::vector<float> sig(steps + 1);
     for (int i = 0; i < steps; ++i) {
@@ -955,20 +1022,59 @@ int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int
         sig[i] = (float)(shift * v / (1.0 + (shift - 1.0) * v));
     }
     sig[steps] = 1.0f;
-    float* x2 = m->v2 + 2 * n;  // [2][n] duplicated latents (CFG batch)
     const bool dedup = g_cfg_dedup && uncond_uniform != 0;
-    const uint16_t* uncond = d_cond2 + (int64_t)m->Lc * m->c.dit_context_dim;
-    for (int i = 0; i < steps; ++i) {
-        if (dedup) {
-            R3G_RC(dit_forward_cfg_dedup(*m, d_latents, sig[i], d_cond2, uncond, m->v2, s));
-        } else {
-            R3G_TRY(hipMemcpyAsync(x2, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
-            R3G_TRY(hipMemcpyAsync(x2 + n, d_latents, n * 4, hipMemcpyDeviceToDevice, s));
-            R3G_RC(dit_forward(*m, x2, nullptr, sig[i], d_cond2, m->v2, 2, -1, -1, s));
+    if (!dedup) {
+        float* x2 = m->v2 + 2 * n;  // [2][n] duplicated latents (CFG batch)
+        for (int o = 0; o < n_objects; ++o) {
+            float* lat = d_latents + o * n;
+            const uint16_t* cond2 = d_cond2 + 2 * o * cond_elems;
+            for (int i = 0; i < steps; ++i) {
+                const float ds = sig[i + 1] - sig[i];
+                if (ds == 0.f && g_skip_zero_step) continue;
+                R3G_TRY(hipMemcpyAsync(x2, lat, n * 4, hipMemcpyDeviceToDevice, s));
+                R3G_TRY(hipMemcpyAsync(x2 + n, lat, n * 4, hipMemcpyDeviceToDevice, s));
+                R3G_RC(dit_forward(*m, x2, nullptr, sig[i], cond2, m->v2, 2, -1, -1, s));
+                R3G_TRY(cfg_euler_launch(lat, m->v2, n, guidance_scale, ds, s));
+            }
         }
-        R3G_TRY(cfg_euler_launch(d_latents, m->v2, n, guidance_scale, sig[i + 1] - sig[i], s));
+        return R3G_OK;
+    }
+    for (int o0 = 0; o0 < n_objects; o0 += kMaxObjects) {
+        const int NB = std::min(kMaxObjects, n_objects - o0);
+        R3G_RC(ensure_dit_batch(*m, NB));
+        Model::DitBatch& d = m->db;
+        const int Ltp = dit_txt_rows(*m);
+        for (int o = 0; o < NB; ++o) {   // context rows of object o: its Lc cond tokens, then ONE unconditional token
+            const uint16_t* cond2 = d_cond2 + 2 * (int64_t)(o0 + o) * cond_elems;
+            uint16_t* dst = d.ctx + (int64_t)o * Ltp * c.dit_context_dim;
+            R3G_TRY(hipMemcpyAsync(dst, cond2, (size_t)cond_elems * 2, hipMemcpyDeviceToDevice, s));
+            R3G_TRY(hipMemcpyAsync(dst + cond_elems, cond2 + cond_elems, (size_t)c.dit_context_dim * 2, hipMemcpyDeviceToDevice, s));
+        }
+        float* lat = d_latents + o0 * n;
+        for (int i = 0; i < steps; ++i) {
+            // the final step of upstream's schedule has d_sigma = 0: its update is x += 0 * v, so the evaluation is skipped
+            // (bit-identical; r3g_set_option("skip_zero_step", 0) evaluates it as upstream does)
+            const float ds = sig[i + 1] - sig[i];
+            if (ds == 0.f && g_skip_zero_step) continue;
+            R3G_RC(dit_forward_cfg_dedup(*m, lat, sig[i], d.v2, NB, s));
+            for (int o = 0; o < NB; ++o) R3G_TRY(cfg_euler_launch(lat + o * n, d.v2 + 2 * o * n, n, guidance_scale, ds, s));
+        }
     }
     return R3G_OK;
+}
+
+int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
+                    float shift, int uncond_uniform, void* stream) {
+    NEED_MODEL("r3g_flow_sample");
+    if (!d_latents || !d_cond2 || steps < 1) return fail(R3G_ERR_INVALID, "r3g_flow_sample: bad argument");
+    return flow_sample(m, d_latents, d_cond2, 1, steps, guidance_scale, shift, uncond_uniform, (hipStream_t)stream);
+}
+
+int r3g_flow_sample_batch(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int n_objects, int steps,
+                          float guidance_scale, float shift, int uncond_uniform, void* stream) {
+    NEED_MODEL("r3g_flow_sample_batch");
+    if (!d_latents || !d_cond2 || steps < 1 || n_objects < 1) return fail(R3G_ERR_INVALID, "r3g_flow_sample_batch: bad argument");
+    return flow_sample(m, d_latents, d_cond2, n_objects, steps, guidance_scale, shift, uncond_uniform, (hipStream_t)stream);
 }
 
 int r3g_vae_decode(r3g_ctx* ctx, const float* d_latents, float* d_z_out, void* stream) {
@@ -1058,6 +1164,7 @@ int r3g_set_option(const char* name, int value) {
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
+    else if (!strcmp(name, "skip_zero_step")) g_skip_zero_step = value != 0;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;

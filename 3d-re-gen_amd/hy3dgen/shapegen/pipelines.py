@@ -72,6 +72,8 @@ def config_from_yaml(doc):
 
 
 class Hunyuan3DDiTPipeline:
+    accepts_image_list = True     # `image` may be a list: its objects share the launches of the denoising loop
+
     def __init__(self, cfg, state_dict, device="cuda", grid_chunk=0, private_ctx=False):
         dev = torch.device(device)
         self.cfg = cfg
@@ -146,23 +148,58 @@ class Hunyuan3DDiTPipeline:
             return torch.randn(shape, generator=generator, device=generator.device, dtype=dt).float().to(self.device)
         return torch.randn((1,) + shape, generator=generator, device="cpu", dtype=dt)[0].float().to(self.device)
 
+    def _latents_for(self, generator, n):
+        """initial latents of n objects, f32 [n, N, C].  One generator (or None): ONE draw of shape (n, N, C), as upstream's
+        prepare_latents does for a list of images; a list of n generators: one (1, N, C) draw each (diffusers.randn_tensor) --
+        object i then gets exactly what a single-image call with generator[i] would give it."""
+        if isinstance(generator, (list, tuple)):
+            if len(generator) != n:
+                raise ValueError("%d generators for %d images" % (len(generator), n))
+            return torch.stack([self.prepare_latents(g) for g in generator], dim=0)
+        shape = (n, self.model.num_latents, self.model.in_channels)
+        dt = torch.float32 if os.environ.get("R3G_NOISE_DTYPE", "float16") == "float32" else torch.float16
+        if generator is not None and generator.device.type != "cpu":
+            return torch.randn(shape, generator=generator, device=generator.device, dtype=dt).float().to(self.device)
+        return torch.randn(shape, generator=generator, device="cpu", dtype=dt).float().to(self.device)
+
+    def generate_latents(self, images, num_inference_steps, guidance_scale, generator):
+        """preprocess + conditioner per image, then ALL objects through the denoising loop together
+        (r3g_flow_sample_batch: every DiT layer is one launch over the objects' rows; per-object results do not depend on
+        the company an object keeps) -> f32 [n, N, C]"""
+        cond2 = torch.stack([self.encode_cond(self.prepare_image(im)["image"]) for im in images], dim=0)
+        latents = self._latents_for(generator, len(images))
+        shift = self.cfg["sched"].get("shift", 1.0)
+        if len(images) == 1:
+            return self.model.flow_sample(latents[0], cond2[0], num_inference_steps, guidance_scale, shift,
+                                          uncond_uniform=True)[None]          # zeros_like(cond)
+        return self.model.flow_sample_batch(latents, cond2, num_inference_steps, guidance_scale, shift, uncond_uniform=True)
+
     def generate_grid(self, image, num_inference_steps, guidance_scale, generator, box_v, octree_resolution):
         import time
         t0 = time.perf_counter()
-        cond_inputs = self.prepare_image(image)
-        cond2 = self.encode_cond(cond_inputs["image"])
-        latents = self.prepare_latents(generator)
-        latents = self.model.flow_sample(latents, cond2, num_inference_steps, guidance_scale,
-                                         self.cfg["sched"].get("shift", 1.0), uncond_uniform=True)  # zeros_like(cond)
+        latents = self.generate_latents([image], num_inference_steps, guidance_scale, generator)[0]
         self.model.vae_decode(latents)
         grid = self.model.grid_query(box_v, octree_resolution)
         self.timings["grid_s"] = time.perf_counter() - t0
         return grid, latents
 
+    def _mesh_from_grid(self, grid, mc_level, box_v, octree_resolution, output_type):
+        try:
+            v, f = self._extract_mesh(grid, mc_level, box_v, octree_resolution)
+        except (ValueError, RuntimeError) as e:   # upstream: traceback + None for this object
+            print("[hy3dgen] surface extraction failed: %s" % e)
+            return None
+        if output_type == "trimesh":
+            return Mesh.from_device(v, f)   # stays in HBM for the cleaners; host arrays on first read
+        return (v, f)
+
     @torch.no_grad()
     def __call__(self, image=None, num_inference_steps=50, timesteps=None, sigmas=None, eta=0.0, guidance_scale=None,
                  generator=None, box_v=None, octree_resolution=384, mc_level=None, mc_algo=None, num_chunks=8000,
                  output_type="trimesh", enable_pbar=True, **kwargs):
+        """image: one PIL image / path (the reference's call, src/2d_to_3d_models/run.py:77-84) or a list of them (upstream's
+        batch dimension): the objects of a list share every launch of the denoising loop and are decoded one after the
+        other; the result has one entry per image."""
         if image is None:
             raise ValueError("image is required")
         if mc_algo not in (None, "mc"):
@@ -171,16 +208,21 @@ class Hunyuan3DDiTPipeline:
         box_v = self.cfg["box_v"] if box_v is None else box_v
         mc_level = self.cfg["mc_level"] if mc_level is None else mc_level
         with self._device_ctx():
+            if isinstance(image, (list, tuple)):
+                import time
+                t0 = time.perf_counter()
+                latents = self.generate_latents(list(image), num_inference_steps, g, generator)
+                out = []
+                for i in range(len(image)):
+                    self.model.vae_decode(latents[i])
+                    grid = self.model.grid_query(box_v, octree_resolution)
+                    self.last_grid = grid
+                    out.append(self._mesh_from_grid(grid, mc_level, box_v, octree_resolution, output_type))
+                self.timings["grid_s"] = time.perf_counter() - t0
+                return out
             grid, latents = self.generate_grid(image, num_inference_steps, g, generator, box_v, octree_resolution)
             self.last_grid = grid
-            try:
-                v, f = self._extract_mesh(grid, mc_level, box_v, octree_resolution)
-            except (ValueError, RuntimeError) as e:   # upstream: traceback + None for this object
-                print("[hy3dgen] surface extraction failed: %s" % e)
-                return [None]
-            if output_type == "trimesh":
-                return [Mesh.from_device(v, f)]   # stays in HBM for the cleaners; host arrays on first read
-            return [(v, f)]
+            return [self._mesh_from_grid(grid, mc_level, box_v, octree_resolution, output_type)]
 
 
 class Hunyuan3DDiTFlowMatchingPipeline(Hunyuan3DDiTPipeline):

@@ -6,13 +6,21 @@ The reference has no collective on this path: it spawns one process per IMAGE an
 (src/2d_to_3d_models/run.py:176-193).  Here
   * broadcast_crops : rank 0 holds the decoded RGBA crops; ONE broadcast of the packed batch (<= 64 crops x 1 MiB) puts
                       them into every rank's memory (HBM under RCCL), so any rank can take any object;
-  * WorkQueue       : a shared counter in the rendezvous store (atomic add on rank 0's TCPStore): a rank claims the next
-                      unprocessed object index when it becomes free -- no static i % num_devices assignment, no straggler
-                      holding back objects another GPU could have taken;
-  * gather_meshes   : per object (index, nV, nF) metadata by all_gather, then point-to-point send / recv of the vertex and
-                      face arrays to rank 0 (variable length, a few hundred KB per cleaned mesh).
-There is no all-reduce anywhere, so nothing here is ring- or bandwidth-bound: scaling is load balance only.
+  * WorkQueue       : a shared counter in a TCPStore this module owns (rank 0 serves it on an ephemeral port that travels
+                      to the other ranks in one broadcast): a rank claims the next unprocessed object indices when it
+                      becomes free -- no static i % num_devices assignment, no straggler holding back objects another
+                      GPU could have taken;
+  * gather_meshes   : per object (index, nV, nF, texture shape) metadata as int64 tensors by all_gather, then
+                      point-to-point send / recv of the vertex and face arrays to rank 0 (variable length, a few
+                      hundred KB per cleaned mesh);
+  * exchange_json   : small host-side records (file names, per-object status) through the same store.
+There is no all-reduce anywhere, so nothing here is ring- or bandwidth-bound: scaling is load balance only.  Nothing
+is pickled through a collective and no private torch API is used; the gloo tests (world 2, 3, 8) run exactly this code --
+the RCCL run differs in the backend string and in where the tensors live.
 """
+import json
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -23,6 +31,14 @@ def _comm_device():
     if dist.get_backend() == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
+
+
+def barrier():
+    """dist.barrier() that names this rank's device under RCCL (no guess from the rank number, no warning)"""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
 
 
 def broadcast_crops(crops, src=0):
@@ -60,27 +76,105 @@ def broadcast_crops(crops, src=0):
     return out
 
 
+# ---- the module's own rendezvous store ---------------------------------------------------------------------------------
+_STORE = None
+_SEQ = [0]      # collective constructions so far (identical on every rank): makes every queue / exchange key unique
+
+
+def side_store():
+    """A TCPStore owned by this module (public API only): rank 0 serves it on an ephemeral port of MASTER_ADDR, the port
+    number reaches the other ranks in one broadcast.  Collective on first use; cached afterwards."""
+    global _STORE
+    if _STORE is not None:
+        return _STORE
+    rank, world = dist.get_rank(), dist.get_world_size()
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    dev = _comm_device()
+    port = torch.zeros(1, dtype=torch.int64, device=dev)
+    master = None
+    if rank == 0:
+        master = dist.TCPStore(host, 0, world, is_master=True, wait_for_workers=False)
+        port[0] = master.port
+    dist.broadcast(port, 0)
+    _STORE = master if rank == 0 else dist.TCPStore(host, int(port.item()), world, is_master=False)
+    return _STORE
+
+
+def reset():
+    """forget the cached store (after destroy_process_group, before a new group in the same process)"""
+    global _STORE
+    _STORE = None
+    _SEQ[0] = 0
+
+
+def _next_key(name):
+    _SEQ[0] += 1
+    return "%s#%d" % (name, _SEQ[0])
+
+
 class WorkQueue:
-    """Dynamic hand-out of object indices 0..n-1 through the process group's store (one atomic add per claim)."""
+    """Dynamic hand-out of object indices 0..n-1 (one atomic add on the store per claim).  Constructing a queue is
+    collective; every instance counts from zero under a key of its own (name + construction sequence number), so a second
+    queue of the same name in the same process group starts fresh."""
 
     def __init__(self, n_items, name="r3g_queue"):
         self.n = int(n_items)
-        self.key = name
         self.store = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from torch.distributed import distributed_c10d as c10d
-            self.store = c10d._get_default_store()
-            dist.barrier()          # every rank has created its handle before the first claim
         self._local = 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.store = side_store()
+            self.key = _next_key(name)
+            if dist.get_rank() == 0:
+                self.store.add(self.key, 0)      # the counter exists (at zero) before anybody claims
+            barrier()
 
     def claim(self):
         """next unclaimed index, or None when the list is exhausted"""
+        got = self.claim_many(1)
+        return got[0] if got else None
+
+    def claim_many(self, k):
+        """the next (at most) k unclaimed indices -- consecutive, one atomic add -- or [] when the list is exhausted"""
+        k = max(1, int(k))
         if self.store is None:
-            i = self._local
-            self._local += 1
+            first = self._local
+            self._local += k
         else:
-            i = int(self.store.add(self.key, 1)) - 1
-        return i if i < self.n else None
+            first = int(self.store.add(self.key, k)) - k
+        return list(range(first, min(first + k, self.n)))
+
+
+def exchange_json(obj, name="r3g_exchange"):
+    """every rank contributes one JSON-serialisable object; every rank gets the list of all of them (index = rank).
+    Host-side records only (names, status lines): they go through the store, not through a collective."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    store = side_store()
+    key = _next_key(name)
+    store.set("%s/%d" % (key, rank), json.dumps(obj))
+    return [json.loads(store.get("%s/%d" % (key, r)).decode()) for r in range(world)]     # get() waits for the key
+
+
+def share_json(obj, src=0, name="r3g_share"):
+    """rank `src`'s object on every rank"""
+    store = side_store()
+    key = _next_key(name)
+    if dist.get_rank() == src:
+        store.set(key, json.dumps(obj))
+    return json.loads(store.get(key).decode())
+
+
+def all_ok(ok):
+    """logical AND over the ranks of a per-rank health flag (a tensor all_gather): lets every rank learn that some rank
+    failed BEFORE it enters a collective the failed rank would never join"""
+    dev = _comm_device()
+    world = dist.get_world_size()
+    mine = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    flags = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(flags, mine)
+    return [bool(int(f.item())) for f in flags]
+
+
+_META = 6   # index, nV, nF, texture shape (3; zeros = no texture)
 
 
 def gather_meshes(local, dst=0):
@@ -99,10 +193,21 @@ def gather_meshes(local, dst=0):
         if len(item) > 3 and item[3] is not None and item[4] is not None:
             uv = torch.as_tensor(item[3]).to(device=dev, dtype=torch.float32).contiguous().view(-1, 2)
             tex = torch.as_tensor(item[4]).to(device=dev, dtype=torch.uint8).contiguous()
+            if tex.ndim != 3:
+                raise ValueError("texture must be [T, T, C]")
         mine.append((int(idx), v, f, uv, tex))
-    meta = [None] * world
-    dist.all_gather_object(meta, [(i, int(v.shape[0]), int(f.shape[0]), None if tex is None else tuple(tex.shape))
-                                  for i, v, f, uv, tex in mine])
+    # metadata: how many meshes per rank, then one int64 row per mesh (padded to the longest list)
+    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(cnt, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
+    counts = [int(c.item()) for c in cnt]
+    width = max(1, max(counts))
+    rows = torch.zeros((width, _META), dtype=torch.int64, device=dev)
+    for k, (i, v, f, uv, tex) in enumerate(mine):
+        rows[k] = torch.tensor([i, v.shape[0], f.shape[0]] + (list(tex.shape) if tex is not None else [0, 0, 0]),
+                               dtype=torch.int64)
+    allrows = [torch.zeros((width, _META), dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allrows, rows)
+    meta = [allrows[r][:counts[r]].cpu().tolist() for r in range(world)]
 
     def pack(v, f, uv, tex):
         return (v.cpu().numpy(), f.cpu().numpy()) if tex is None else (v.cpu().numpy(), f.cpu().numpy(), uv.cpu().numpy(),
@@ -114,7 +219,7 @@ def gather_meshes(local, dst=0):
         for r in range(world):
             if r == dst:
                 continue
-            for (i, nv, nf, tshape) in meta[r]:       # the sender walks the same list in the same order
+            for (i, nv, nf, t0, t1, t2) in meta[r]:       # the sender walks the same list in the same order
                 v = torch.empty((nv, 3), dtype=torch.float32, device=dev)
                 f = torch.empty((nf, 3), dtype=torch.int32, device=dev)
                 if nv:
@@ -122,13 +227,13 @@ def gather_meshes(local, dst=0):
                 if nf:
                     dist.recv(f, src=r)
                 uv = tex = None
-                if tshape is not None:
+                if t0 * t1 * t2:
                     uv = torch.empty((nv, 2), dtype=torch.float32, device=dev)
-                    tex = torch.empty(tshape, dtype=torch.uint8, device=dev)
+                    tex = torch.empty((t0, t1, t2), dtype=torch.uint8, device=dev)
                     if nv:
                         dist.recv(uv, src=r)
                     dist.recv(tex, src=r)
-                out[i] = pack(v, f, uv, tex)
+                out[int(i)] = pack(v, f, uv, tex)
     else:
         for i, v, f, uv, tex in mine:
             if v.shape[0]:

@@ -54,6 +54,7 @@ SYMBOLS = {
     "r3g_dit_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "r3g_dit_stream": (_I, [_P, _P, _I, _P]),
     "r3g_flow_sample": (_I, [_P, _P, _P, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
+    "r3g_flow_sample_batch": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
     "r3g_vae_decode": (_I, [_P, _P, _P, _P]),
     "r3g_grid_query": (_I, [_P, _D, _I, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),

@@ -174,6 +174,21 @@ class ShapeModel:
                                             float(guidance_scale), float(shift), int(bool(uncond_uniform)), self._s()))
         return latents
 
+    def flow_sample_batch(self, latents, cond2, steps, guidance_scale, shift=1.0, uncond_uniform=None):
+        """n independent objects through the denoising loop together: latents f32 [n,N,C] (modified in place and
+        returned), cond2 bf16 [n,2,Lc,D].  Per-object results equal flow_sample() of that object bit for bit."""
+        latents = latents.to(self.device, torch.float32).contiguous()
+        cond2 = cond2.to(self.device, torch.bfloat16).contiguous()
+        if latents.ndim != 3 or cond2.ndim != 4 or cond2.shape[0] != latents.shape[0] or cond2.shape[1] != 2:
+            raise ValueError("flow_sample_batch: latents [n,N,C] and cond2 [n,2,Lc,D] expected")
+        if uncond_uniform is None:
+            uncond_uniform = bool((cond2[:, 1] == cond2[:, 1, :1]).all().item())
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_flow_sample_batch(self.ctx, latents.data_ptr(), cond2.data_ptr(), int(latents.shape[0]),
+                                                  int(steps), float(guidance_scale), float(shift),
+                                                  int(bool(uncond_uniform)), self._s()))
+        return latents
+
     def vae_decode(self, latents, return_z=False):
         latents = latents.to(self.device, torch.float32).contiguous()
         z = torch.empty((self.num_latents, self.cfg["vae"]["width"]), dtype=torch.float32, device=self.device) \

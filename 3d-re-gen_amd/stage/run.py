@@ -122,13 +122,27 @@ def clean_and_validate_mesh(mesh, min_faces=10, target_face_count=None):
     return mesh
 
 
-def generate_mesh(image, base, shapegen, texgen, cleaners, config):
-    """reference process_image :69-97 without the file I/O around it: RGBA image -> cleaned (and textured) mesh"""
+def objects_per_launch(config):
+    """private key `r3g_objects_per_launch` (default 2): how many crops share the launches of the denoising loop.  The DiT's
+    GEMMs have 7.5 k rows per object; two objects give every layer enough rows for 256x256 tiles on all 256 CUs.  Results
+    do not depend on it (bit-identical per object)."""
+    return max(1, int(config.get("r3g_objects_per_launch", 2)))
+
+
+def shape_meshes(images, shapegen, config):
+    """reference :77-84 for a group of images: the raw marching-cubes meshes, in order (None where extraction failed).
+    Every object gets a generator seeded with cfg.seed, exactly as the reference seeds each of its calls (:82)."""
     import torch
-    print("Processing %s..." % base)
-    mesh = shapegen(image=image, num_inference_steps=config.get("num_inf_steps_hy", 100),
-                    octree_resolution=config.get("octree_resolution_hy", 380), num_chunks=config.get("num_chunks_hy", 20000),
-                    generator=torch.manual_seed(config.get("seed", 12345)), output_type="trimesh")[0]
+    kw = dict(num_inference_steps=config.get("num_inf_steps_hy", 100), octree_resolution=config.get("octree_resolution_hy", 380),
+              num_chunks=config.get("num_chunks_hy", 20000), output_type="trimesh")
+    seed = config.get("seed", 12345)
+    if len(images) > 1 and getattr(shapegen, "accepts_image_list", False):
+        return list(shapegen(image=list(images), generator=[torch.Generator().manual_seed(seed) for _ in images], **kw))
+    return [shapegen(image=im, generator=torch.manual_seed(seed), **kw)[0] for im in images]
+
+
+def finish_mesh(mesh, image, texgen, cleaners, config):
+    """reference process_image :86-97: optional remesh, the three cleaners, the texture stage"""
     if mesh is None:
         raise RuntimeError("surface extraction produced no mesh")
     if config.get("remesh", False):
@@ -138,6 +152,50 @@ def generate_mesh(image, base, shapegen, texgen, cleaners, config):
         mesh = cleaner(mesh)
     print("Cleaned mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
     return texgen(mesh, image=image)
+
+
+def generate_mesh(image, base, shapegen, texgen, cleaners, config):
+    """reference process_image :69-97 without the file I/O around it: RGBA image -> cleaned (and textured) mesh"""
+    print("Processing %s..." % base)
+    return finish_mesh(shape_meshes([image], shapegen, config)[0], image, texgen, cleaners, config)
+
+
+def generate_group(images, bases, shapegen, texgen, cleaners, config, isolate):
+    """A group of crops through the shape pipeline together, then one by one through cleaners + texture stage.
+    -> [(mesh or None, error or None, seconds)] in order.  isolate: an exception does not leave the group (the object is
+    reported as failed; a failure of the shared shape launch is retried object by object so that one bad crop cannot
+    take its neighbours down); otherwise the first exception propagates, as in the reference's sequential path."""
+    t0 = time.time()
+    for b in bases:
+        print("Processing %s..." % b)
+    try:
+        raw = shape_meshes(images, shapegen, config)
+        errs = [None] * len(images)
+    except Exception as e:
+        if not isolate:
+            raise
+        raw, errs = [], []
+        for im in images:
+            try:
+                raw.append(shape_meshes([im], shapegen, config)[0] if len(images) > 1 else None)
+                errs.append(None if len(images) > 1 else e)
+            except Exception as e1:
+                raw.append(None)
+                errs.append(e1)
+    t_shape = (time.time() - t0) / max(1, len(images))
+    out = []
+    for im, m, err in zip(images, raw, errs):
+        t1 = time.time()
+        if err is not None:
+            out.append((None, err, t_shape))
+            continue
+        try:
+            out.append((finish_mesh(m, im, texgen, cleaners, config), None, t_shape + time.time() - t1))
+        except Exception as e:
+            if not isolate:
+                raise
+            out.append((None, e, t_shape + time.time() - t1))
+    return out
 
 
 def export_mesh(mesh, base, output_dir):
@@ -167,69 +225,96 @@ def partition(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _stem(path):
+    return os.path.splitext(os.path.basename(path))[0]
+
+
 def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_errors):
-    """Sequential path (one process): load the model once, process every image, return [(index, path, status, seconds)]."""
+    """Sequential path (one process): load the model once, process the images in groups of `r3g_objects_per_launch`,
+    return [(index, path, status, seconds)]."""
     import torch
+    from PIL import Image
     device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu"
     shapegen, texgen, cleaners = factory(config, device)
     results = []
-    for i in partition(len(image_paths), rank, world):
-        t0 = time.time()
-        try:
-            process_image(image_paths[i], shapegen, texgen, cleaners, output_folder, config)
-            results.append((i, image_paths[i], "ok", time.time() - t0))
-        except Exception as e:
-            if not swallow_errors:
-                raise
-            print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
-            results.append((i, image_paths[i], "error: %s" % e, time.time() - t0))
+    todo = partition(len(image_paths), rank, world)
+    B = objects_per_launch(config)
+    for g0 in range(0, len(todo), B):
+        idx = todo[g0:g0 + B]
+        images = [Image.open(image_paths[i]).convert("RGBA") for i in idx]
+        bases = [_stem(image_paths[i]) for i in idx]
+        for i, base, (mesh, err, secs) in zip(idx, bases, generate_group(images, bases, shapegen, texgen, cleaners, config,
+                                                                          isolate=swallow_errors)):
+            if err is None:
+                out_path = export_mesh(mesh, base, output_folder)
+                print("Saved %s to %s in %.2f seconds." % (base, out_path, secs))
+                results.append((i, image_paths[i], "ok", secs))
+            else:
+                print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
+                results.append((i, image_paths[i], "error: %s" % err, secs))
     return results, texture_state(texgen)
 
 
 def run_distributed(config, input_folder, output_folder, rank, world, factory):
     """One persistent rank per GPU.  Rank 0 decodes the crops and broadcasts the packed batch (RCCL: into every rank's
-    HBM); ranks claim object indices from a shared counter as they become free, keep their meshes, and rank 0 gathers
-    and writes them.  Returns (results, textured) on rank 0, (None, None) elsewhere."""
+    HBM); ranks claim object indices from a shared counter as they become free (`r3g_objects_per_launch` at a time), keep
+    their meshes, and rank 0 gathers and writes them.  A rank whose setup or loop dies (model load, out of memory, ...)
+    still joins every collective: its finished meshes are delivered, the objects it had claimed are reported as failed,
+    and the stage's exit code says so.  Returns (results, textured, failed_ranks) on rank 0, (None, None, failed_ranks)
+    elsewhere."""
     import numpy as np
     import torch
-    import torch.distributed as dist
     from PIL import Image
     from r3g import dist as rdist
     from r3g.mesh import Mesh
     device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu"
-    names = [None]
     crops = None
+    image_paths = None
     if rank == 0:
         image_paths = list_images(input_folder)
-        names = [image_paths]
         crops = [np.asarray(Image.open(p).convert("RGBA")) for p in image_paths]
-    dist.broadcast_object_list(names, src=0)          # the file names only (the pixels travel as tensors below)
-    image_paths = names[0]
-    crops = rdist.broadcast_crops(crops, src=0)
+    image_paths = rdist.share_json(image_paths, src=0, name="r3g_stage_names")    # the file names only
+    crops = rdist.broadcast_crops(crops, src=0)                                     # the pixels travel as one tensor
     queue = rdist.WorkQueue(len(image_paths), name="r3g_stage_objects")
-    shapegen, texgen, cleaners = factory(config, device)
     # r3g_stream_outputs: every rank writes `<out>/<stem>/<stem>.glb` the moment the object is done (a consumer such as the
     # scene-reconstruction stage can start per object, SURVEY 8f rank 4) instead of returning the mesh to rank 0; the files
     # are the same bytes either way (the writer is deterministic)
     stream_out = bool(config.get("r3g_stream_outputs", False))
+    B = objects_per_launch(config)
     mine, status = [], []
-    while True:
-        i = queue.claim()
-        if i is None:
-            break
-        base = os.path.splitext(os.path.basename(image_paths[i]))[0]
-        t0 = time.time()
-        try:
-            image = Image.fromarray(crops[i].cpu().numpy(), "RGBA")
-            mesh = generate_mesh(image, base, shapegen, texgen, cleaners, config)
-            if stream_out:
-                export_mesh(mesh, base, output_folder)
-            else:
-                mine.append((i, mesh))
-            status.append((i, image_paths[i], "ok", time.time() - t0, rank))
-        except Exception as e:      # one object failing must not fail the stage (reference :135-136 swallows it silently)
-            print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
-            status.append((i, image_paths[i], "error: %s" % e, time.time() - t0, rank))
+    rank_error = None
+    texgen = None
+    claimed = []
+    try:
+        shapegen, texgen, cleaners = factory(config, device)
+        while True:
+            claimed = queue.claim_many(B)
+            if not claimed:
+                break
+            images = [Image.fromarray(crops[i].cpu().numpy(), "RGBA") for i in claimed]
+            bases = [_stem(image_paths[i]) for i in claimed]
+            # one object failing must not fail the stage (reference :135-136 swallows it silently)
+            for i, base, (mesh, err, secs) in zip(claimed, bases, generate_group(images, bases, shapegen, texgen, cleaners,
+                                                                                  config, isolate=True)):
+                if err is None:
+                    if stream_out:
+                        export_mesh(mesh, base, output_folder)
+                    else:
+                        mine.append((i, mesh))
+                    status.append((i, image_paths[i], "ok", secs, rank))
+                else:
+                    print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
+                    status.append((i, image_paths[i], "error: %s" % err, secs, rank))
+            claimed = []
+    except BaseException as e:      # rank-level failure: keep what is finished, report what was in flight, stay collective
+        rank_error = e
+        print("ERROR on rank %d (rank-level, outside the per-object handling): %r" % (rank, e), file=sys.stderr)
+        done = {s[0] for s in status}
+        for i in claimed:
+            if i not in done:
+                status.append((i, image_paths[i], "error: rank %d failed: %s" % (rank, e), 0.0, rank))
+    ok_flags = rdist.all_ok(rank_error is None)
+    failed_ranks = [r for r, ok in enumerate(ok_flags) if not ok]
     local = []
     for i, mesh in mine:
         if getattr(mesh, "_dv", None) is not None:
@@ -238,15 +323,20 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
             local.append((i, np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32),
                           getattr(mesh, "uv", None), getattr(mesh, "texture", None)))     # textured: uv + PNG source pixels too
     gathered = rdist.gather_meshes(local, dst=0)
-    all_status = [None] * world
-    dist.all_gather_object(all_status, status)
+    all_status = rdist.exchange_json(status, name="r3g_stage_status")
     if rank != 0:
-        return None, None
+        return None, None, failed_ranks
     for i in sorted(gathered):
         g = gathered[i]
         mesh = Mesh(g[0], g[1]) if len(g) == 2 else Mesh(g[0], g[1], uv=g[2], texture=g[3])
-        export_mesh(mesh, os.path.splitext(os.path.basename(image_paths[i]))[0], output_folder)
-    return sorted(r for part in all_status for r in part), texture_state(texgen)
+        export_mesh(mesh, _stem(image_paths[i]), output_folder)
+    results = sorted(tuple(r) for part in all_status for r in part)
+    # objects nobody reported (claimed by a rank that died before it could say so) are failures, not silence
+    seen = {r[0] for r in results}
+    for i in range(len(image_paths)):
+        if i not in seen:
+            results.append((i, image_paths[i], "error: not processed (ranks %s failed)" % failed_ranks, 0.0, -1))
+    return sorted(results), texture_state(texgen) if texgen is not None else (True, None), failed_ranks
 
 
 def main(argv=None, factory=default_factory):
@@ -286,18 +376,26 @@ def main(argv=None, factory=default_factory):
     backend = "nccl" if torch.cuda.is_available() else "gloo"
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend)
+    from r3g import dist as rdist
+    if torch.cuda.is_available():
+        dist.init_process_group(backend, device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        dist.init_process_group(backend)
     rc = 0
     try:
         if rank == 0 and not os.environ.get("R3G_STAGE_PREPARED"):
             os.makedirs(output_folder, exist_ok=True)
             clear_output_directory(output_folder)
-        dist.barrier()
-        results, textured = run_distributed(config, input_folder, output_folder, rank, world, factory)
+        rdist.barrier()
+        results, textured, failed_ranks = run_distributed(config, input_folder, output_folder, rank, world, factory)
         if rank == 0:
             rc = finish(report(results, textured), config)
             print("All parallel tasks completed.")
+        if failed_ranks:      # a rank-level failure (not a per-object one) is a setup error: non-zero, on every rank
+            print("[r3g] rank(s) %s failed outside the per-object handling" % failed_ranks, file=sys.stderr)
+            rc = rc or 4
     finally:
+        rdist.reset()
         dist.destroy_process_group()
     return rc
 

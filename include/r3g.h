@@ -204,6 +204,13 @@ int r3g_dit_stream(r3g_ctx* ctx, float* d_out, int batch, void* stream);
  * function with 31 % fewer rows in that batch entry (switch "cfg_dedup" of r3g_set_option turns this off). */
 int r3g_flow_sample(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int steps, float guidance_scale,
                     float shift, int uncond_uniform, void* stream);
+/* The same loop for n_objects independent objects (upstream: the pipeline's batch dimension when `image` is a list; the
+ * reference gets object-level parallelism from its worker pool, src/2d_to_3d_models/run.py:176-193): d_latents f32
+ * [n_objects][num_latents][in_channels] in/out, d_cond2 bf16 [n_objects][2][tokens][dim].  With uncond_uniform the objects
+ * share every DiT launch (up to 4 per launch; the GEMMs then have enough rows for 256x256 tiles on every layer); each
+ * object's result is bit-identical to what r3g_flow_sample gives for it alone. */
+int r3g_flow_sample_batch(r3g_ctx* ctx, float* d_latents, const uint16_t* d_cond2, int n_objects, int steps,
+                          float guidance_scale, float shift, int uncond_uniform, void* stream);
 
 /* ShapeVAE.forward(latents / scale_factor) (post_kl + transformer) and the geo decoder's K/V of the
  * result (computed once; upstream recomputes them for every chunk).  d_z_out (optional) f32
@@ -246,7 +253,8 @@ int r3g_prof_read_bytes(double* bytes, int n);
 /* A/B switches for tests and ablations.  Default 1: "fuse_qkv" (QKV split/norm/transpose in the projection epilogue
  * vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch), "lds_dma"
  * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
- * txt stream of a double block in one GEMM / LayerNorm launch), "overlap_mlp" (0 default | 1: MLP half of a single block's linear1
+ * txt stream of a double block in one GEMM / LayerNorm launch), "skip_zero_step" (the DiT evaluation of a step with d_sigma = 0 --
+ * upstream's last step -- is skipped: x += 0 * v), "overlap_mlp" (0 default | 1: MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
  * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 two-stage | 10 = 256x128 | 11 = 256x256 phased | 12 = phased,
  * persistent grid | 13 = phased, deterministic split-K over two workgroups per tile | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"

@@ -135,7 +135,7 @@ def make_distinct_scene(tmp_path, n):
     return cfg, inp, out, names
 
 
-def _run_ranks(tmp_path, cfg, world, port, factory_name="fake_factory"):
+def _run_ranks(tmp_path, cfg, world, port, factory_name="fake_factory", expect_rc=0):
     driver = tmp_path / ("drv%d.py" % world)
     driver.write_text(textwrap.dedent("""
         import importlib.util, os, sys
@@ -157,8 +157,9 @@ def _run_ranks(tmp_path, cfg, world, port, factory_name="fake_factory"):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(port), str(driver)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if expect_rc is not None:
+        assert (r.returncode == 0) == (expect_rc == 0), r.stdout + r.stderr
     return r
 
 
@@ -249,3 +250,111 @@ def test_broadcast_crops_and_gather_roundtrip_single_process(tmp_path):
         assert rdist.broadcast_crops([]) == []
     finally:
         dist.destroy_process_group()
+
+
+def test_world_of_eight_ranks_gloo(tmp_path):
+    """the driver's 8-GPU run, on the CPU: 8 ranks, 19 objects claimed two at a time from the shared counter, crops by
+    one broadcast, meshes back point to point -- byte-identical to the one-rank run.  This is the code the RCCL run
+    executes; only the backend string and the device of the tensors differ."""
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 19)
+    _run_ranks(tmp_path, cfg, 1, 0, "content_factory")
+    one = _glbs(out)
+    r = _run_ranks(tmp_path, cfg, 8, 29660, "content_factory")
+    assert _glbs(out) == one and len(one) == 19
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 19 and rep["ok"] == 19
+    assert len(set(rep["rank_of_object"])) >= 4          # the queue really spread the work
+
+
+def batch_factory(config, device):
+    """stand-in that takes a LIST of images like the real pipeline (accepts_image_list) and records the group sizes"""
+    s, t, c = content_factory(config, device)
+
+    class Batched:
+        accepts_image_list = True
+        groups = []
+
+        def __call__(self, image=None, generator=None, **kw):
+            if isinstance(image, (list, tuple)):
+                assert isinstance(generator, list) and len(generator) == len(image)
+                assert len({g.initial_seed() for g in generator}) == 1 and len({id(g) for g in generator}) == len(image)
+                Batched.groups.append(len(image))
+                return [s(image=im, generator=g, **kw)[0] for im, g in zip(image, generator)]
+            Batched.groups.append(1)
+            return s(image=image, generator=generator, **kw)
+    return Batched(), t, c
+
+
+def test_objects_per_launch_groups_give_the_same_files(tmp_path):
+    """r3g_objects_per_launch: crops go through the shape pipeline in groups (one generator per object, each seeded with
+    cfg.seed as the reference seeds every call); the files do not depend on the group size"""
+    stage = load_stage()
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 5)
+    assert stage.main(["--config", cfg], factory=content_factory) == 0
+    ref = _glbs(out)
+    for per, want in ((1, [1, 1, 1, 1, 1]), (2, [2, 2, 1]), (4, [4, 1])):
+        conf = yaml.safe_load(open(cfg))
+        conf["r3g_objects_per_launch"] = per
+        open(cfg, "w").write(yaml.safe_dump(conf))
+        seen = {}
+
+        def factory(config, device):
+            sgen, t, c = batch_factory(config, device)
+            type(sgen).groups.clear()
+            seen["s"] = sgen
+            return sgen, t, c
+        assert stage.main(["--config", cfg], factory=factory) == 0
+        assert type(seen["s"]).groups == want
+        assert _glbs(out) == ref
+
+
+def dying_factory(config, device):
+    """rank 1 cannot load its model (the ADVICE scenario: an out-of-memory on one GPU)"""
+    if os.environ.get("RANK") == "1":
+        raise MemoryError("synthetic: model load failed on this rank")
+    return content_factory(config, device)
+
+
+def test_a_rank_that_dies_at_model_load_does_not_hang_the_others(tmp_path):
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 6)
+    r = _run_ranks(tmp_path, cfg, 3, 29670, "dying_factory", expect_rc=4)
+    assert r.returncode != 0                                   # a rank-level failure is visible in the exit code
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 6 and rep["ok"] == 6            # the surviving ranks took every object
+    assert sorted(os.listdir(out)) == sorted(n[:-4] for n in names)
+    assert "rank(s) [1] failed" in r.stderr
+
+
+def test_work_queues_of_the_same_name_start_fresh(tmp_path):
+    """ADVICE: a second WorkQueue with the same name must not continue the first one's count (two ranks, gloo)"""
+    drv = tmp_path / "q.py"
+    drv.write_text(textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from r3g import dist as rdist
+        dist.init_process_group("gloo")
+        got = []
+        for n in (5, 4):
+            q = rdist.WorkQueue(n, name="same")
+            mine = []
+            while True:
+                c = q.claim_many(2)
+                if not c:
+                    break
+                mine += c
+            got.append(mine)
+        allgot = rdist.exchange_json(got)
+        if dist.get_rank() == 0:
+            first = sorted(i for g in allgot for i in g[0]); second = sorted(i for g in allgot for i in g[1])
+            assert first == [0, 1, 2, 3, 4] and second == [0, 1, 2, 3], (first, second)
+            print("QUEUES_OK")
+        assert rdist.all_ok(True) == [True, True]
+        assert rdist.share_json({"a": [1, 2]} if dist.get_rank() == 0 else None) == {"a": [1, 2]}
+        rdist.barrier()
+        dist.destroy_process_group()
+    """ % os.path.join(ROOT, "3d-re-gen_amd")))
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29680", str(drv)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "QUEUES_OK" in r.stdout, r.stdout + r.stderr
