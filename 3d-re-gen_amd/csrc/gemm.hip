@@ -1694,7 +1694,7 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
 
 static int g_gemm_waves = 0;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
-int g_gemm_auto_rule = 1, g_num_cu = 256;
+int g_gemm_auto_rule = 2, g_num_cu = 256;
 bool g_gemm_splitk = false;      // deterministic split-K for deep-K residual GEMMs on under-filled grids (measured: no gain)
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
@@ -1718,8 +1718,11 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             // A CU keeps ~20 B/clk of operand loads in flight (L1 miss queue x L2 latency, profiles/r01_pmc_gemm_counters.md):
             // the 256x256 tile needs half the bytes per flop of the 128x128 one and wins wherever its coarser grid
             // still fills the machine; otherwise 128x128 with 8 waves (4 per SIMD at two workgroups per CU).
+            // rule 2 (round 3): also any launch whose 256x256 grid fills >= 85 % of the CUs in full rounds -- the N = 1024
+            // residual GEMMs of the DiT once two or more objects share a launch (236 tiles; one object: 120, stays 128x128)
+            const bool wide_enough = p.N >= 4096 || (g_gemm_auto_rule >= 2 && t256 * 100 >= (long)g_num_cu * 85);
             if ((p2.M == 0 || p2.N % 256 == 0) && p.N % 256 == 0 && t256 >= 128 &&
-                (p.K >= 2048 || t256 >= 2048 || (p.N >= 4096 && fills)))
+                (p.K >= 2048 || t256 >= 2048 || (wide_enough && fills)))
                 waves = g_gemm_phased ? 11 : 9;   // phased 256x256 kernel (falls back to 8 waves when K % 128 != 0)
             else waves = 8;
         }

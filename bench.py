@@ -7,7 +7,9 @@
 
 A "step" is ONE object: a synthetic 512x512 RGBA crop (host PIL image, as the segmentation stage hands it over)
 -> preprocess -> DINOv2-g conditioner -> 50-step flow-matching DiT with CFG (batch 2) -> shape-VAE decode ->
-dense 257^3 occupancy-grid query -> Lewiner marching cubes, mesh left in HBM.  Model load, mesh cleaners,
+dense 257^3 occupancy-grid query -> Lewiner marching cubes, mesh left in HBM.  The crops of a scene are independent:
+--objects-per-launch of them (default 2) share the launches of the denoising loop (upstream's batch dimension; each
+object's result is bit-identical to its single-object run, tests/test_model_gpu.py), everything else runs per object.  Model load, mesh cleaners,
 texture generation and GLB export are outside the metric.  Workload at N=1 = BASELINE.json
 configs[1] ("1 scene / 8 object crops, Hunyuan3D-2 base bf16, 50 steps, 256^3 grid"): the default --steps 8 is
 one scene.  Weights are seeded synthetic (no checkpoint / network here); the arithmetic is the full model's.
@@ -22,8 +24,12 @@ reported as "strong".
 Rank 0 prints one JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel family (bf16 MFMA GEMM), timed live with HIP events on the launch stream
                  over one further object: achieved = sum of algorithmic FLOPs / sum of launch durations
+  roofline_mc  : the HBM-bound kernel of the path (marching cubes): algorithmic bytes 4 (R+1)^3 + 12 V + 12 F over its
+                 measured time, against the 8 TB/s HBM peak
   cpu_baseline : the PyTorch-CPU fp32 oracle + the C marching-cubes oracle timed on this box's host cores on a
                  bounded sample of the same workload and extrapolated (rank 0, N=1 only)
+  mc_parity    : the last timed object's mesh (faces AND float32 vertices) against the C oracle's mesh of the same grid,
+                 computed for the CPU baseline anyway: "exact" or the run fails
 """
 import argparse
 import ctypes
@@ -48,10 +54,21 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def recorded_traffic(family):
+    """the PMC record of a kernel family + whether it was measured on the library this run loaded (source digest)"""
     try:
         with open(TRAFFIC_FILE) as f:
             rec = json.load(f)
-        return rec.get(family)
+        fam = rec.get(family)
+        if fam is None:
+            return None
+        fam = dict(fam)
+        try:
+            with open(os.path.join(ROOT, "3d-re-gen_amd", "libr3g.digest")) as f:
+                now = f.read().strip()
+        except OSError:
+            now = None
+        fam["stale"] = not (now and rec.get("library_digest") == now)
+        return fam
     except (OSError, ValueError):
         return None
 
@@ -133,8 +150,9 @@ def cpu_baseline(cfg, steps, R, grid_np):
     pts = torch.from_numpy(H.dense_grid_points(1.01, R)[:chunk])[None]
     t_chunk = tm(lambda: pipe.vae.geo_decoder(queries=pts, latents=z[0]))
     t0 = time.perf_counter()
+    oracle_mesh = None
     try:
-        omc.hy3d_mesh(grid_np, 0.0, 1.01, R)
+        oracle_mesh = omc.hy3d_mesh(grid_np, 0.0, 1.01, R)
     except (ValueError, RuntimeError):
         pass
     t_mc = time.perf_counter() - t0
@@ -142,7 +160,7 @@ def cpu_baseline(cfg, steps, R, grid_np):
     t_obj = (steps * (d["depth"] * t_d + d["depth_single_blocks"] * t_s + t_io) + v["num_decoder_layers"] * t_vae +
              cfg["cond"]["num_hidden_layers"] * t_cond + n_chunks * t_chunk + t_mc)
     measured = spent[0] + t_mc
-    return {"value": 1.0 / t_obj, "unit": "objects/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return oracle_mesh, {"value": 1.0 / t_obj, "unit": "objects/sec", "cores": torch.get_num_threads(), "kind": "port",
             "extrapolated": True, "seconds_per_object": t_obj, "cpu_seconds_measured": measured,
             "sample": "fp32 oracle at full widths: 1 double + 1 single DiT block (CFG batch 2, 4442 tokens), 1 VAE layer, "
                       "1 DINOv2-g layer, 1 chunk of 16000 grid queries, C marching cubes on the full %d^3 grid; "
@@ -157,6 +175,8 @@ def main():
     ap.add_argument("--model", default="full", choices=["full", "mini"])
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--octree-resolution", type=int, default=256)
+    ap.add_argument("--objects-per-launch", type=int, default=2,
+                    help="crops that share the launches of the denoising loop (1 = one object at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp8-geo", action="store_true",
@@ -193,7 +213,8 @@ def main():
         ffi.check(ffi.lib().r3g_set_option(b"geo_fp8", 1))
     cfg = pipe.cfg
     S, R = a.inference_steps, a.octree_resolution
-    n_local = a.warmup + a.steps + 1
+    B = max(1, a.objects_per_launch)
+    n_local = a.warmup + a.steps + B      # + one further group for the event-timed (roofline) pass
     from PIL import Image
     if dist is None:
         crops = [synthetic_crop(j) for j in range(n_local)]   # host PIL images (the stage's input format)
@@ -204,26 +225,32 @@ def main():
         dev_crops = rdist.broadcast_crops(packed, src=0)
         crops = [Image.fromarray(dev_crops[rank + world * j].cpu().numpy(), "RGBA") for j in range(n_local)]
 
-    def one(img):
-        return pipe(image=img, num_inference_steps=S, octree_resolution=R, num_chunks=16000,
-                    generator=torch.manual_seed(1234567), output_type="raw")[0]
+    def group(imgs):
+        """one launch group: every object gets a generator seeded with the reference's cfg.seed (src/config.yaml:29)"""
+        if len(imgs) == 1:
+            return pipe(image=imgs[0], num_inference_steps=S, octree_resolution=R, num_chunks=16000,
+                        generator=torch.manual_seed(1234567), output_type="raw")
+        return pipe(image=list(imgs), num_inference_steps=S, octree_resolution=R, num_chunks=16000,
+                    generator=[torch.Generator().manual_seed(1234567) for _ in imgs], output_type="raw")
+
+    def run(imgs):
+        out_ = []
+        for g0 in range(0, len(imgs), B):
+            out_ += group(imgs[g0:g0 + B])
+        return out_
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            rdist.barrier()
         torch.cuda.synchronize()
 
-    for j in range(a.warmup):
-        one(crops[j])
+    run(crops[:a.warmup])
     barrier()
     t0 = time.perf_counter()
-    last = None
-    made = []
-    for j in range(a.steps):
-        last = one(crops[a.warmup + j])
-        if dist is not None:
-            made.append((rank + world * (a.warmup + j), last[0], last[1]))
+    meshes = run(crops[a.warmup:a.warmup + a.steps])       # EXACTLY a.steps objects
+    last = meshes[-1] if meshes else None
     if dist is not None:       # the meshes travel to rank 0 over RCCL (point-to-point, variable length)
+        made = [(rank + world * (a.warmup + j), m[0], m[1]) for j, m in enumerate(meshes) if m is not None]
         gathered = rdist.gather_meshes(made, dst=0)
         if rank == 0 and len(gathered) != world * a.steps:
             raise SystemExit("gather_meshes returned %d of %d meshes" % (len(gathered), world * a.steps))
@@ -231,6 +258,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    last_grid = pipe.last_grid
     if dist is not None:
         tt = torch.tensor([dt], device=rdist._comm_device(), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -238,18 +266,19 @@ def main():
 
     strong = None
     if dist is not None:
-        # strong scaling: configs[1]'s 8 crops in total, claimed dynamically (r3g.dist.WorkQueue), meshes gathered
-        total_s = min(8, len(dev_crops))     # (8 unless a very short run broadcast fewer crops)
+        # strong scaling: a FIXED total of 8 crops per GPU of the node (configs[2]: 8 scenes x 8 objects on 8 GPUs), claimed
+        # dynamically B at a time (r3g.dist.WorkQueue), meshes gathered -- enough objects per rank for the queue to balance
+        total_s = 8 * world
         q = rdist.WorkQueue(total_s, name="bench_strong")
         barrier()
         t1 = time.perf_counter()
         mine = []
         while True:
-            i = q.claim()
-            if i is None:
+            idx = q.claim_many(B)
+            if not idx:
                 break
-            m = one(Image.fromarray(dev_crops[i].cpu().numpy(), "RGBA"))
-            mine.append((i, m[0], m[1]))
+            ms_ = group([Image.fromarray(dev_crops[i % len(dev_crops)].cpu().numpy(), "RGBA") for i in idx])
+            mine += [(i, m[0], m[1]) for i, m in zip(idx, ms_) if m is not None]
         got = rdist.gather_meshes(mine, dst=0)
         torch.cuda.synchronize()
         barrier()
@@ -258,7 +287,7 @@ def main():
         if rank == 0:
             assert len(got) == total_s
             strong = {"objects_total": total_s, "seconds": float(ts.item()), "value": total_s / float(ts.item()),
-                      "unit": "objects/sec", "assignment": "dynamic queue"}
+                      "unit": "objects/sec", "assignment": "dynamic queue, %d per claim" % B}
         del got, mine
 
     out = None
@@ -271,7 +300,7 @@ def main():
                "config": {"workload": "configs[1]: %d synthetic 512x512 RGBA crops per GPU, Hunyuan3D-2 %s dims bf16, "
                                       "%d flow-matching steps x CFG 2, %d^3 grid query + Lewiner marching cubes"
                                       % (a.steps, a.model, S, R + 1),
-                          "weights": "seeded synthetic", "objects_total": total,
+                          "weights": "seeded synthetic", "objects_total": total, "objects_per_launch": B,
                           "parallelism": "object-parallel x%d" % world},
                "flops_per_object": flops_per_object(cfg, S, R),
                "mesh_last": None if last is None else {"V": int(last[0].shape[0]), "F": int(last[1].shape[0])}}
@@ -289,7 +318,7 @@ def main():
         overlap_on = "overlap_mlp=1" in os.environ.get("R3G_OPTIONS", "")
         ffi.check(L.r3g_set_option(b"overlap_mlp", 0))
         ffi.check(L.r3g_prof_enable(1))
-        one(crops[a.warmup + a.steps])
+        prof_meshes = run(crops[a.warmup + a.steps:a.warmup + a.steps + B])       # one further launch group of B objects
         torch.cuda.synchronize()
         ffi.check(L.r3g_set_option(b"overlap_mlp", 1 if overlap_on else 0))
         n = len(FAMILIES)
@@ -298,7 +327,8 @@ def main():
         alg = (ctypes.c_double * n)()
         ffi.check(L.r3g_prof_read_bytes(alg, n))
         ffi.check(L.r3g_prof_enable(0))
-        fam = {FAMILIES[i]: {"launches": int(cnt[i]), "ms": float(ms[i]), "work": float(work[i])} for i in range(n)}
+        # per OBJECT: the event-timed pass ran one group of B objects
+        fam = {FAMILIES[i]: {"launches": int(cnt[i]), "ms": float(ms[i]) / B, "work": float(work[i]) / B} for i in range(n)}
         dom = max(("gemm", "attention"), key=lambda k: fam[k]["ms"])
         ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12 if fam[dom]["ms"] > 0 else 0.0
         executed = fam["gemm"]["work"] + fam["attention"]["work"]      # FLOPs the MFMA kernels actually issued
@@ -310,20 +340,47 @@ def main():
                            "traffic": None if tr is None else tr.get("bytes_per_launch"),
                            "traffic_source": None if tr is None else
                            "profiles/traffic.json (%s, commit %s)" % (tr.get("measured"), tr.get("commit")),
+                           # True: the PMC record was measured on a different build of libr3g.so than this run loaded
+                           "traffic_stale": None if tr is None else bool(tr.get("stale")),
                            "algorithmic_bytes_per_launch": (float(alg[FAMILIES.index(dom)]) / max(1, fam[dom]["launches"])
                                                             if dom == "gemm" else None),
                            "launches": fam[dom]["launches"],
-                           "avg_launch_us": 1000.0 * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
-                           "note": "per-launch HIP events on one extra object (one stream: kernels run alone)",
+                           "avg_launch_us": 1000.0 * B * fam[dom]["ms"] / max(1, fam[dom]["launches"]),
+                           "note": "per-launch HIP events on one extra launch group of %d objects (one stream: kernels run "
+                                   "alone); families_ms_per_object = group time / %d" % (B, B),
                            "families_ms_per_object": {k: round(v["ms"], 3) for k, v in fam.items()},
                            "attention_tflops": (fam["attention"]["work"] / (fam["attention"]["ms"] * 1e-3) / 1e12
                                                 if fam["attention"]["ms"] > 0 else 0.0),
                            "mc_classify_gbps": (fam["mc_classify"]["work"] / (fam["mc_classify"]["ms"] * 1e-3) / 1e9
                                                 if fam["mc_classify"]["ms"] > 0 else 0.0)}
+        # the HBM-bound kernel family of the path: marching cubes on the resident grid (one read of the grid + one
+        # write of the mesh); V, F of the last object of the event-timed group
+        mc_ms = fam["mc_classify"]["ms"] + fam["mc_other"]["ms"]
+        prof_meshes = [m for m in prof_meshes if m is not None]
+        if prof_meshes and mc_ms > 0:
+            mc_bytes = 4.0 * (R + 1) ** 3 + 12.0 * sum(int(m[0].shape[0]) + int(m[1].shape[0]) for m in prof_meshes) / len(prof_meshes)
+            out["roofline_mc"] = {"kernel": "marching cubes (classify + scan + vertices + faces)", "bound": "hbm",
+                                  "achieved": mc_bytes / (mc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                  "frac": mc_bytes / (mc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "ms": mc_ms,
+                                  "algorithmic_bytes": mc_bytes,
+                                  "note": "synthetic weights give a noise-like field: V and F are ~5x a real object's"}
+    bad = False
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, S, R, pipe.last_grid.cpu().numpy())
+        oracle_mesh, out["cpu_baseline"] = cpu_baseline(cfg, S, R, last_grid.cpu().numpy())
+        # the C oracle's mesh of the last TIMED object's grid against the mesh the timed region produced
+        if oracle_mesh is None or last is None:
+            out["mc_parity"] = "no surface"
+        else:
+            ov, of = oracle_mesh
+            gv, gf = last[0].cpu().numpy(), last[1].cpu().numpy()
+            same = (gv.shape == ov.shape and gf.shape == of.shape and np.array_equal(gf.astype(np.int64), of.astype(np.int64))
+                    and np.array_equal(gv.astype(np.float32).view(np.uint32), ov.astype(np.float32).view(np.uint32)))
+            out["mc_parity"] = "exact" if same else "MISMATCH"
+            bad = not same
     if rank == 0:
         print(json.dumps(out))
+    if bad:
+        raise SystemExit("bench.py: the timed object's mesh differs from the marching-cubes oracle's mesh of the same grid")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

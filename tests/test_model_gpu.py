@@ -163,6 +163,152 @@ def test_flow_sample_matches_restated_scheduler(tiny):
     assert torch.equal(trace[-1], trace[-2])
 
 
+def _fifty_steps(s, tag, seed):
+    """50 Euler steps x CFG 2 (the reference's num_inf_steps_hy, src/config.yaml) against the oracle's sampler: the stated
+    SURVEY 8(c) tolerance for 50-step latents is 3e-2 rel-L2"""
+    import torch
+    x, _, cond = _inputs(s, seed)
+    lat0 = x[0]
+    ref = s.oracle.sample(cond, lat0[None].clone(), 50, 5.0)[0]
+    out = s.gpu.flow_sample(lat0.clone(), cond, 50, 5.0)
+    assert torch.isfinite(out).all()
+    err = rel_l2(out, ref)
+    report("%s flow_sample 50 steps x CFG (guidance 5)" % tag, err, TOL["flow_sample_50"])
+    return err, out, lat0, cond
+
+
+def test_flow_sample_fifty_steps_tiny(tiny):
+    err, out, lat0, cond = _fifty_steps(tiny, "tiny", 31)
+    assert err <= TOL["flow_sample_50"]
+    # the sampler moved the latents by O(1): the tolerance is not met by standing still
+    assert rel_l2(out, lat0) > 0.3
+
+
+def test_flow_sample_fifty_steps_mini_dims():
+    """hunyuan3d-dit-v2-mini dims (full width, 8 + 16 blocks, 512 latents + 1370 context tokens), 50 steps x CFG 2"""
+    from oracle import hy3d_torch as H
+    cfg = H.mini_config()
+    cfg["vae"].update(num_decoder_layers=1)
+    cfg["cond"].update(num_hidden_layers=1)
+    s = Setup(cfg, 41)
+    err, out, lat0, _ = _fifty_steps(s, "mini-dims", 5)
+    assert err <= TOL["flow_sample_50"]
+    assert rel_l2(out, lat0) > 0.3
+
+
+def test_fifty_steps_full_width_dedup_against_plain_batch(wide):
+    """50 steps at full width (4442 tokens, depth 1 + 1): the de-duplicated CFG batch against the plain one -- two valid
+    bf16 evaluations of the same sampler -- and both against the oracle"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x, _, cond = _inputs(wide, 15)
+    lat0 = x[0]
+    a = wide.gpu.flow_sample(lat0.clone(), cond, 50, 5.0).clone()
+    try:
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 0))
+        b = wide.gpu.flow_sample(lat0.clone(), cond, 50, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
+    report("full-width 50 steps: cfg dedup vs plain batch", rel_l2(a, b), TOL["same_function"])
+    assert rel_l2(a, b) <= TOL["same_function"]
+    ref = wide.oracle.sample(cond, lat0[None].clone(), 50, 5.0)[0]
+    ea, eb = rel_l2(a, ref), rel_l2(b, ref)
+    report("full-width 1+1 flow_sample 50 steps (dedup)", ea, TOL["flow_sample_50"])
+    report("full-width 1+1 flow_sample 50 steps (plain batch)", eb, TOL["flow_sample_50"])
+    assert ea <= TOL["flow_sample_50"] and eb <= TOL["flow_sample_50"]
+
+
+def test_skipping_the_zero_step_changes_nothing(tiny):
+    """upstream's last step has d_sigma = 0; its DiT evaluation is skipped by default (x += 0 * v)"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x, _, cond = _inputs(tiny, 8)
+    a = tiny.gpu.flow_sample(x[0].clone(), cond, 7, 5.0).clone()
+    try:
+        ffi.check(L.r3g_set_option(b"skip_zero_step", 0))
+        b = tiny.gpu.flow_sample(x[0].clone(), cond, 7, 5.0).clone()
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 0))
+        c = tiny.gpu.flow_sample(x[0].clone(), cond, 7, 5.0).clone()
+        ffi.check(L.r3g_set_option(b"skip_zero_step", 1))
+        d = tiny.gpu.flow_sample(x[0].clone(), cond, 7, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"skip_zero_step", 1))
+        ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
+    assert torch.equal(a, b) and torch.equal(c, d)
+
+
+def _batch_inputs(s, n, seed):
+    import torch
+    from parity_support import dit_inputs
+    lats, conds = [], []
+    for o in range(n):
+        x, _, cond = dit_inputs(s.cfg, seed + 7 * o)
+        lats.append(x[0])
+        conds.append(cond)
+    return torch.stack(lats), torch.stack(conds).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("which,n", [("tiny", 2), ("tiny", 3), ("tiny", 4), ("tiny", 5), ("wide", 2), ("wide", 4)])
+def test_objects_sharing_a_launch_get_bit_identical_results(which, n, tiny, wide):
+    """r3g_flow_sample_batch: n objects go through every DiT layer in one launch (more rows: the full-width GEMMs move from
+    128x128 to 256x256 tiles, the attention grid gets 2n entries, 5 objects = a launch of 4 and one of 1).  A row does
+    not know its neighbours: each object's latents must equal its single-object run BIT FOR BIT."""
+    import torch
+    st = tiny if which == "tiny" else wide
+    lat, cond = _batch_inputs(st, n, 100)
+    steps = 3 if which == "tiny" else 2
+    single = [st.gpu.flow_sample(lat[o].clone(), cond[o], steps, 5.0).clone() for o in range(n)]
+    both = st.gpu.flow_sample_batch(lat.clone(), cond, steps, 5.0)
+    assert not torch.equal(single[0], single[1])
+    for o in range(n):
+        assert torch.equal(both[o], single[o]), "object %d of %d differs: max |d| %.3e" % (
+            o, n, float((both[o] - single[o]).abs().max()))
+    # and against the oracle, object 1 (the batch path is the one under test)
+    ref = st.oracle.sample(cond[1].float(), lat[1][None].clone(), steps, 5.0)[0]
+    assert rel_l2(both[1], ref) <= TOL["flow_sample"]
+    # plain (non-dedup) contexts: the batch entry point falls back to one object after the other
+    cond_nu = cond.clone()
+    cond_nu[:, 1] = torch.randn_like(cond_nu[:, 1].float()).to(torch.bfloat16)
+    if which == "tiny":
+        c = st.gpu.flow_sample_batch(lat.clone(), cond_nu, 2, 2.0)
+        for o in range(n):
+            assert torch.equal(c[o], st.gpu.flow_sample(lat[o].clone(), cond_nu[o], 2, 2.0))
+
+
+def test_pipeline_takes_a_list_of_images():
+    """upstream's batch dimension: pipe(image=[...]) -> one mesh per image; with one generator per image every object is
+    what its own single-image call gives (grids bit-identical, hence meshes identical)"""
+    import torch
+    from PIL import Image
+    from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
+    from oracle import hy3d_torch as H
+    cfg = H.tiny_config()
+    sd = bf16_round_matrices(H.synthetic_state_dict(cfg, seed=5))
+    pipe = Hunyuan3DDiTFlowMatchingPipeline(cfg, sd, "cuda:0", grid_chunk=2048)
+    rng = np.random.default_rng(3)
+    imgs = []
+    for k in range(3):
+        arr = np.zeros((90, 80, 4), np.uint8)
+        arr[15 + k:70, 10:60 - 3 * k, :3] = rng.integers(0, 255, (55 - k, 50 - 3 * k, 3))
+        arr[15 + k:70, 10:60 - 3 * k, 3] = 255
+        imgs.append(Image.fromarray(arr, "RGBA"))
+    kw = dict(num_inference_steps=4, octree_resolution=24, num_chunks=999, output_type="trimesh")
+    singles, grids = [], []
+    for im in imgs:
+        singles.append(pipe(image=im, generator=torch.manual_seed(77), **kw)[0])
+        grids.append(pipe.last_grid.clone())
+    many = pipe(image=imgs, generator=[torch.Generator().manual_seed(77) for _ in imgs], **kw)
+    assert len(many) == 3 and torch.equal(pipe.last_grid, grids[2])
+    for a, b in zip(singles, many):
+        assert np.array_equal(a.faces, b.faces) and np.array_equal(a.vertices, b.vertices)
+    assert not np.array_equal(singles[0].vertices, singles[1].vertices)
+    # ONE generator for the list: one draw of shape (n, N, C), upstream's prepare_latents
+    one = pipe(image=imgs[:2], generator=torch.manual_seed(77), **kw)
+    assert len(one) == 2 and all(m is not None and len(m.faces) > 0 for m in one)
+
+
 def test_vae_and_grid_query(tiny):
     import torch
     g = torch.Generator().manual_seed(7)

@@ -48,6 +48,51 @@ def test_stage_script_writes_glbs(tmp_path):
     assert rep["textured"] is True and "input view only" in rep["texture_source"]
 
 
+def test_configs1_literally_eight_crops_full_model(tmp_path):
+    """BASELINE.json configs[1] as written: 1 scene / 8 object crops, Hunyuan3D-2 base dims at FULL depth (16 + 32 blocks,
+    DINOv2-g 40 layers, VAE 16 layers), 50 steps x CFG 2, 256^3 octree grid, through the drop-in stage script (reference
+    call src/2d_to_3d_models/run.py:77-84 with src/config.yaml's values); every GLB is checked."""
+    sys.path.insert(0, ROOT)
+    from bench import synthetic_crop
+    from r3g.mesh import load_glb
+    from gltf_validate import validate_glb
+    inp, out = tmp_path / "prepped", tmp_path / "out"
+    inp.mkdir()
+    for i in range(8):
+        synthetic_crop(i).save(inp / ("obj__(%d, %d).png" % (i, 10 * i)))
+    cfg = {"mini": False, "num_inf_steps_hy": 50, "octree_resolution_hy": 256, "num_chunks_hy": 16000, "seed": 1234567,
+           "remesh": False, "input_folder_hy": str(tmp_path / "unused"), "output_folder_hy": str(out), "use_banana": True,
+           "prepped_for_hunyuan": str(inp), "jobs_per_gpu": 1, "use_all_available_cuda": False,
+           "r3g_weights": "synthetic:{model}"}
+    cfgp = tmp_path / "config.yaml"
+    cfgp.write_text(yaml.safe_dump(cfg))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "3d-re-gen_amd", "stage", "run.py"), "--config", str(cfgp)],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(out)) == sorted("obj__(%d, %d)" % (i, 10 * i) for i in range(8))
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 8 and rep["ok"] == 8 and rep["failed"] == []
+    distinct = set()
+    for stem in os.listdir(out):
+        data = (out / stem / (stem + ".glb")).read_bytes()
+        got = validate_glb(data)
+        m = load_glb(str(out / stem / (stem + ".glb")))
+        assert 1000 < len(m.faces) <= 40000                                      # FaceReducer's bound, and a real surface
+        assert np.array_equal(got["indices"].astype(np.int64), m.faces) and len(got["positions"]) == len(m.vertices)
+        assert int(m.faces.max()) < len(m.vertices) and int(m.faces.min()) >= 0
+        assert np.isfinite(m.vertices).all() and np.abs(m.vertices).max() <= 1.02   # inside upstream's box_v = 1.01 box
+        assert got["image"] is not None and "TEXCOORD_0" in got["attributes"]
+        distinct.add(hash(m.vertices.tobytes()))
+    assert len(distinct) == 8                                    # eight different crops gave eight different meshes
+    from parity_support import report
+    report("configs[1] literal: stage script wall seconds for 8 crops (incl. model load)", wall, 1e9)
+    report("configs[1] literal: mean seconds per object inside the stage", float(np.mean(rep["seconds"])), 1e9)
+
+
 def test_octree_resolution_512_end_to_end():
     """SURVEY config 4's grid size (513^3 = 135 M points, a 15 M-vertex mesh) through grid query, marching cubes and the
     cleaners, on tiny model dims so that it takes seconds; marching cubes still bit-exact against the oracle."""
