@@ -16,8 +16,12 @@ if os.environ.get("R3G_TEST_SNAPSHOT"):
         return path
     huggingface_hub.snapshot_download = _snapshot_download
 
+for _p in filter(None, os.environ.get("R3G_TEST_EXTRA_PATH", "").split(os.pathsep)):
+    if _p not in sys.path:      # (the orchestrator test: reference run.py:72-86 REPLACES PYTHONPATH for the stage it spawns)
+        sys.path.append(_p)
+
 if os.environ.get("R3G_TEST_CPU_SHIM") == "1":
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.path.dirname(os.path.realpath(__file__))     # (this file may be reached through a symlink)
     sys.path.insert(0, os.path.dirname(here))
     import ref_shim
     ref_shim.install()
