@@ -1184,7 +1184,9 @@ static int g_attn_gen = 7;
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
 constexpr int kWide6MinItems = 2048;
 void attn_set_generation(int gen) { if (gen >= 1 && gen <= 7) g_attn_gen = gen; }
-float attn_q_scale(float scale) { return g_attn_gen >= 2 ? scale * 1.4426950408889634f : 1.0f; }
+// (the first-generation kernels -- attn_generation 1 and the attn_pipelined option -- scale the scores themselves and
+// reject a pre-scaled Q: producers must then leave q plain)
+float attn_q_scale(float scale) { return (g_attn_gen >= 2 && !g_attn_pipelined) ? scale * 1.4426950408889634f : 1.0f; }
 
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
     if (p.ragged) {

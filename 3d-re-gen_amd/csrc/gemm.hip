@@ -20,7 +20,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 #include "prof.h"
@@ -1622,25 +1625,35 @@ hipError_t launch_gemm8(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
     return hipGetLastError();
 }
 
-// split-K workspace: one slot of 256 KiB + 8 flags per tile, for at most kSplitMaxTiles tiles; one launch at a time may use
-// it (the launches that take this path are all on the model's main stream)
+// split-K workspace: one slot of 256 KiB + 8 flags per tile, for at most kSplitMaxTiles tiles, per (device, stream): two
+// contexts / streams that use the option at the same time get workspaces (and epochs) of their own
 constexpr int kSplitMaxTiles = 128;
-static float* g_split_ws = nullptr;
-static unsigned* g_split_flags = nullptr;
-static unsigned g_split_epoch = 0;
+struct SplitWs { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; };
+static std::mutex g_split_mutex;
+static std::map<std::pair<int, hipStream_t>, SplitWs> g_split;
 
 template <int EPI>
 hipError_t launch_gemm8_split(const GemmArgs& p, const GemmArgs& p2, hipStream_t s) {
     int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
     if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
     if (tiles > kSplitMaxTiles) return hipErrorNotSupported;
-    if (!g_split_ws) {
-        hipError_t e = hipMalloc((void**)&g_split_ws, (size_t)kSplitMaxTiles * 256 * 256 * 4);
-        if (e != hipSuccess) return e;
-        e = hipMalloc((void**)&g_split_flags, (size_t)kSplitMaxTiles * 8 * 4);
-        if (e != hipSuccess) return e;
-        e = hipMemset(g_split_flags, 0, (size_t)kSplitMaxTiles * 8 * 4);
-        if (e != hipSuccess) return e;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    SplitWs w;
+    {
+        std::lock_guard<std::mutex> lock(g_split_mutex);
+        SplitWs& slot = g_split[std::make_pair(dev, s)];
+        if (!slot.ws) {
+            e = hipMalloc((void**)&slot.ws, (size_t)kSplitMaxTiles * 256 * 256 * 4);
+            if (e != hipSuccess) return e;
+            e = hipMalloc((void**)&slot.flags, (size_t)kSplitMaxTiles * 8 * 4);
+            if (e != hipSuccess) return e;
+            e = hipMemset(slot.flags, 0, (size_t)kSplitMaxTiles * 8 * 4);
+            if (e != hipSuccess) return e;
+        }
+        if (++slot.epoch == 0u) slot.epoch = 1u;   // 0 is the flags' initial value
+        w = slot;
     }
     const size_t lds = 131072;
     auto k = gemm8_kernel<EPI, true>;
@@ -1649,8 +1662,7 @@ hipError_t launch_gemm8_split(const GemmArgs& p, const GemmArgs& p2, hipStream_t
         done = true;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (++g_split_epoch == 0u) g_split_epoch = 1u;   // 0 is the flags' initial value
-    hipLaunchKernelGGL(k, dim3(2 * tiles), dim3(512), lds, s, p, p2, g_split_ws, g_split_flags, g_split_epoch);
+    hipLaunchKernelGGL(k, dim3(2 * tiles), dim3(512), lds, s, p, p2, w.ws, w.flags, w.epoch);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ namespace r3g {
 // workspace for any of the three cleaners on a mesh of nv vertices / nf faces (max_cells: clustering grid, 0 if unused)
 size_t mesh_workspace_bytes(int64_t nv, int64_t nf, int64_t max_cells);
 int mesh_reduce_initial_res(int64_t max_faces);
+void mesh_set_floater_by_vertex(bool on);   // 0 (default): faces joined through shared edges (MeshLab) | 1: through shared vertices
 
 // All three compact verts / faces in place (survivors keep their order) and update *nv_io / *nf_io.
 // They synchronise the stream internally (sizes travel through the pinned h_small, >= 32 bytes).

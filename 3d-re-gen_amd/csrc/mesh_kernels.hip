@@ -154,6 +154,55 @@ __global__ void uf_hook_kernel(const int32_t* __restrict__ faces, int64_t nf, in
     uf_union(parent, a, c);
 }
 
+// ---- faces joined through shared EDGES (MeshLab's face-face adjacency: two parts that touch in a single vertex are two
+// components).  Pass 1: every undirected edge (min vertex, max vertex) goes into an open-addressing table, its slot keeps the
+// SMALLEST face id that has the edge (atomicMin: independent of scheduling).  Pass 2: every face unites itself with the
+// owner of each of its edges -- all faces around an edge (two, or more on a non-manifold edge) end up in one set.
+constexpr unsigned long long kEdgeEmpty = ~0ull;
+__device__ __forceinline__ unsigned long long edge_key(int a, int b) {
+    const unsigned lo = (unsigned)(a < b ? a : b), hi = (unsigned)(a < b ? b : a);
+    return ((unsigned long long)lo << 32) | hi;
+}
+__device__ __forceinline__ uint64_t edge_hash(unsigned long long k) {   // splitmix64 finaliser
+    k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+    k ^= k >> 27; k *= 0x94d049bb133111ebull;
+    return k ^ (k >> 31);
+}
+__global__ void edge_insert_kernel(const int32_t* __restrict__ faces, int64_t nf, unsigned long long* __restrict__ keys,
+                                   int* __restrict__ owner, uint64_t mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const int v[3] = {faces[3 * i], faces[3 * i + 1], faces[3 * i + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int a = v[e], b = v[(e + 1) % 3];
+        if (a == b) continue;                       // a collapsed side of a degenerate face joins nothing
+        const unsigned long long k = edge_key(a, b);
+        uint64_t slot = edge_hash(k) & mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&keys[slot], kEdgeEmpty, k);
+            if (prev == kEdgeEmpty || prev == k) { atomicMin(&owner[slot], (int)i); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+__global__ void edge_union_kernel(const int32_t* __restrict__ faces, int64_t nf, const unsigned long long* __restrict__ keys,
+                                  const int* __restrict__ owner, uint64_t mask, int* __restrict__ parent) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const int v[3] = {faces[3 * i], faces[3 * i + 1], faces[3 * i + 2]};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int a = v[e], b = v[(e + 1) % 3];
+        if (a == b) continue;
+        const unsigned long long k = edge_key(a, b);
+        uint64_t slot = edge_hash(k) & mask;
+        while (keys[slot] != k) slot = (slot + 1) & mask;     // present: pass 1 put it there
+        const int o = owner[slot];
+        if (o != (int)i) uf_union(parent, (int)i, o);
+    }
+}
+
 // roots never change here (nothing links any more), so every chain ends in its final root
 __global__ void uf_flatten_kernel(int* __restrict__ parent, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,11 +214,13 @@ __global__ void uf_flatten_kernel(int* __restrict__ parent, int64_t n) {
 
 // Faces per component.  Most faces of a wave belong to the same (large) component, and same-address atomics
 // serialise in L2: lanes with equal roots are merged first (one atomic per distinct root per wave).
+// BY_FACE: root[] is indexed by the face (edge-joined components), otherwise by the face's first vertex
+template <bool BY_FACE>
 __global__ void comp_count_kernel(const int32_t* __restrict__ faces, int64_t nf, const int* __restrict__ root,
                                   unsigned* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int r = i < nf ? root[faces[3 * i]] : -1;
+    int r = i < nf ? root[BY_FACE ? i : (int64_t)faces[3 * i]] : -1;
     unsigned long long todo = __ballot(r >= 0);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -193,6 +244,7 @@ __global__ void max_u32_kernel(const unsigned* __restrict__ v, int64_t n, unsign
 
 // keep[f] = faces-of-component >= max(1, (unsigned)(min_ratio * largest)): MeshLab's small-component selection removes the
 // components with fewer faces than the TRUNCATED product (compute_selection_by_small_disconnected_components_per_face)
+template <bool BY_FACE>
 __global__ void floater_flag_kernel(const int32_t* __restrict__ faces, int64_t nf, const int* __restrict__ root,
                                     const unsigned* __restrict__ cnt, const unsigned* __restrict__ largest,
                                     double min_ratio, unsigned* __restrict__ keep) {
@@ -200,7 +252,7 @@ __global__ void floater_flag_kernel(const int32_t* __restrict__ faces, int64_t n
     if (i >= nf) return;
     const double t = floor(min_ratio * (double)*largest);
     const unsigned thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
-    keep[i] = cnt[root[faces[3 * i]]] >= thr ? 1u : 0u;
+    keep[i] = cnt[root[BY_FACE ? i : (int64_t)faces[3 * i]]] >= thr ? 1u : 0u;
 }
 
 __global__ void nondegenerate_flag_kernel(const int32_t* __restrict__ faces, int64_t nf, unsigned* __restrict__ keep) {
@@ -471,6 +523,14 @@ size_t mesh_workspace_bytes(int64_t nv, int64_t nf, int64_t max_cells) {
     add(24 * (size_t)nv);          // cluster sums
     add(4 * (size_t)nv);           // cluster counts
     add(256);                      // small results
+    {   // floater removal through shared edges: face parents / counts + the edge table (released before the compaction)
+        int64_t cap = 64;
+        while (cap < 6 * nf) cap <<= 1;
+        size_t e = 0;
+        auto adde = [&](size_t bytes) { e += (bytes + 255) & ~(size_t)255; };
+        adde(64); adde(4 * (size_t)nf); adde(4 * (size_t)nf); adde(4 * (size_t)nf); adde(8 * (size_t)cap); adde(4 * (size_t)cap);
+        if (e > b) b = e;
+    }
     // the edge-collapse decimator (qem_driver.h Buffers)
     size_t q = 0;
     auto addq = [&](size_t bytes) { q += (bytes + 255) & ~(size_t)255; };
@@ -511,6 +571,15 @@ static hipError_t compact_mesh(Arena& ar, float* verts, int64_t nv, int32_t* fac
     return hipSuccess;
 }
 
+static bool g_floater_by_vertex = false;   // option "floater_by_vertex": rounds 1-2 joined components through shared vertices
+void mesh_set_floater_by_vertex(bool on) { g_floater_by_vertex = on; }
+
+static int64_t edge_table_slots(int64_t nf) {
+    int64_t cap = 64;
+    while (cap < 6 * nf) cap <<= 1;      // 3 nf edge insertions at most: load factor <= 0.5
+    return cap;
+}
+
 hipError_t mesh_remove_floaters(char* ws, size_t ws_bytes, unsigned* h_small, float* verts, int64_t* nv_io,
                                 int32_t* faces, int64_t* nf_io, double min_ratio, hipStream_t s) {
     const int64_t nv = *nv_io, nf = *nf_io;
@@ -518,19 +587,46 @@ hipError_t mesh_remove_floaters(char* ws, size_t ws_bytes, unsigned* h_small, fl
     ProfScope ps(PC_MESH, 12.0 * (double)(nv + nf), s);
     Arena ar = {ws, 0, ws_bytes};
     unsigned* d_small = ar.take<unsigned>(16);
-    int* parent = ar.take<int>(nv);
-    unsigned* cnt = ar.take<unsigned>(nv);
-    unsigned* keep = ar.take<unsigned>(nf);
     R3G_HIP(hipMemsetAsync(d_small, 0, 64, s));
-    R3G_HIP(hipMemsetAsync(cnt, 0, 4 * (size_t)nv, s));
-    hipLaunchKernelGGL(iota_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, parent, nv);
-    hipLaunchKernelGGL(uf_hook_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf, parent);
-    hipLaunchKernelGGL(uf_flatten_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, parent, nv);
-    hipLaunchKernelGGL(comp_count_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
-                       (const int*)parent, cnt);
-    hipLaunchKernelGGL(max_u32_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, (const unsigned*)cnt, nv, d_small + 2);
-    hipLaunchKernelGGL(floater_flag_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
-                       (const int*)parent, (const unsigned*)cnt, (const unsigned*)(d_small + 2), min_ratio, keep);
+    unsigned* keep = ar.take<unsigned>(nf);
+    if (g_floater_by_vertex) {
+        // round 1 / 2 semantics: components joined through shared vertices
+        int* parent = ar.take<int>(nv);
+        unsigned* cnt = ar.take<unsigned>(nv);
+        R3G_HIP(hipMemsetAsync(cnt, 0, 4 * (size_t)nv, s));
+        hipLaunchKernelGGL(iota_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, parent, nv);
+        hipLaunchKernelGGL(uf_hook_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf, parent);
+        hipLaunchKernelGGL(uf_flatten_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, parent, nv);
+        hipLaunchKernelGGL(comp_count_kernel<false>, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
+                           (const int*)parent, cnt);
+        hipLaunchKernelGGL(max_u32_kernel, dim3(nblocks(nv, kT)), dim3(kT), 0, s, (const unsigned*)cnt, nv, d_small + 2);
+        hipLaunchKernelGGL(floater_flag_kernel<false>, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
+                           (const int*)parent, (const unsigned*)cnt, (const unsigned*)(d_small + 2), min_ratio, keep);
+    } else {
+        // MeshLab's semantics: faces joined through shared edges (union-find over FACES, edge -> smallest face table)
+        const int64_t cap = edge_table_slots(nf);
+        int* parent = ar.take<int>(nf);
+        unsigned* cnt = ar.take<unsigned>(nf);
+        unsigned long long* keys = ar.take<unsigned long long>(cap);
+        int* owner = ar.take<int>(cap);
+        if (ar.off > ar.cap) return hipErrorOutOfMemory;
+        R3G_HIP(hipMemsetAsync(cnt, 0, 4 * (size_t)nf, s));
+        R3G_HIP(hipMemsetAsync(keys, 0xFF, 8 * (size_t)cap, s));
+        R3G_HIP(hipMemsetAsync(owner, 0x7F, 4 * (size_t)cap, s));      // 0x7F7F7F7F: above every face id
+        hipLaunchKernelGGL(iota_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, parent, nf);
+        hipLaunchKernelGGL(edge_insert_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf, keys, owner,
+                           (uint64_t)(cap - 1));
+        hipLaunchKernelGGL(edge_union_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
+                           (const unsigned long long*)keys, (const int*)owner, (uint64_t)(cap - 1), parent);
+        hipLaunchKernelGGL(uf_flatten_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, parent, nf);
+        hipLaunchKernelGGL(comp_count_kernel<true>, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
+                           (const int*)parent, cnt);
+        hipLaunchKernelGGL(max_u32_kernel, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const unsigned*)cnt, nf, d_small + 2);
+        hipLaunchKernelGGL(floater_flag_kernel<true>, dim3(nblocks(nf, kT)), dim3(kT), 0, s, (const int32_t*)faces, nf,
+                           (const int*)parent, (const unsigned*)cnt, (const unsigned*)(d_small + 2), min_ratio, keep);
+        // the tables are dead from here on: compact_mesh may reuse their space
+        ar.off = (size_t)(reinterpret_cast<char*>(parent) - ar.base);
+    }
     R3G_HIP(hipGetLastError());
     return compact_mesh(ar, verts, nv, faces, nf, keep, d_small, h_small, nv_io, nf_io, s);
 }

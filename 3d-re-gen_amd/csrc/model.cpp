@@ -25,6 +25,7 @@
 
 #include "../../include/r3g.h"
 #include "kernels.h"
+#include "mesh_kernels.h"
 #include "prof.h"
 #include "r3g_ctx.h"
 
@@ -1182,6 +1183,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
     else if (!strcmp(name, "ln_rows")) ln_set_rows_per_wave(value);
     else if (!strcmp(name, "ln_fixed")) ln_set_fixed_count(value != 0);
+    else if (!strcmp(name, "floater_by_vertex")) mesh_set_floater_by_vertex(value != 0);
     else if (!strcmp(name, "mc_rows")) mc_set_rows_per_wave(value);
     else if (!strcmp(name, "mc_deferred")) mc_set_deferred(value != 0);
     else if (!strcmp(name, "lds_dma")) { gemm_set_glds(value != 0); attn_set_glds(value != 0); }

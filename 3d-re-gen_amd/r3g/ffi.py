@@ -127,6 +127,20 @@ def new_context(device=0):
     return h
 
 
+_LOCKS = {}
+_LOCKS_GUARD = __import__("threading").Lock()
+
+
+def device_lock(device=0):
+    """One re-entrant lock per device for calls that go through the SHARED context: its mesh / texture workspaces and its
+    pinned read-back buffer belong to one call at a time.  Pipelines with private contexts run their shape model
+    concurrently, but their threads still meet in the mesh cleaners and the texture stage, which use the shared context."""
+    with _LOCKS_GUARD:
+        if device not in _LOCKS:
+            _LOCKS[device] = __import__("threading").RLock()
+        return _LOCKS[device]
+
+
 def context(device=0):
     """The process-wide r3g_ctx of a device (created on first use)."""
     if device not in _CTX:

@@ -25,8 +25,10 @@ def _prepare(verts, faces):
 def _run(fn, verts, faces, *extra):
     v, f = _prepare(verts, faces)
     nv, nf = ctypes.c_int64(v.shape[0]), ctypes.c_int64(f.shape[0])
-    ctx = ffi.context(v.device.index or 0)
-    with torch.cuda.device(v.device):
+    dev = v.device.index or 0
+    # the shared context's workspace and read-back buffer: one call at a time (the entry points synchronise the stream)
+    with ffi.device_lock(dev), torch.cuda.device(v.device):
+        ctx = ffi.context(dev)
         ffi.check(fn(ctx, ctypes.c_void_p(v.data_ptr()), ctypes.byref(nv), ctypes.c_void_p(f.data_ptr()),
                      ctypes.byref(nf), *extra, _stream_ptr()))
     return v[:nv.value], f[:nf.value]

@@ -17,12 +17,33 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _locked(sync):
+    """the shared context's texture workspace (z-buffer, inpainting buffers) belongs to one call at a time; `sync`: the
+    call leaves kernels behind that still use it, so the stream is drained before the next caller may enter"""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kw):
+            first = next(a for a in list(args) + list(kw.values()) if isinstance(a, torch.Tensor))
+            if not first.is_cuda:
+                return fn(*args, **kw)          # the function raises the "no CPU path" error itself
+            with ffi.device_lock(first.device.index or 0):
+                out = fn(*args, **kw)
+                if sync:
+                    torch.cuda.current_stream(first.device).synchronize()
+                return out
+        return wrapper
+    return deco
+
+
 def _dev(t, dtype, what):
     if not t.is_cuda:
         raise ValueError("%s must live on the GPU (there is no CPU path)" % what)
     return t.detach().to(dtype).contiguous()
 
 
+@_locked(True)
 def rasterize(pos_clip, tri, height, width):
     """pos_clip float32 [V, 4] (clip space), tri int32 [F, 3] -> findices int32 [H, W] (face + 1; 0 = empty),
     bary float32 [H, W, 3] (perspective-correct)"""
@@ -114,6 +135,7 @@ def bake_finalize(acc):
     return tex, mask
 
 
+@_locked(False)
 def inpaint(texture, mask, findices_uv, bary_uv, verts, pos_tri, uv, uv_tri, dilate_iters=8):
     """-> (texture, mask, propagation rounds); mask: 1 painted by a view, 2 filled from vertex colours, 3 dilated, 0 empty"""
     tex = _dev(texture, torch.float32, "texture").clone()

@@ -78,10 +78,11 @@ int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xf
  * one CPU thread) on the device buffers r3g_mc_emit filled: d_verts float32 [*n_verts][3], d_faces int32
  * [*n_faces][3].  Each call compacts both arrays in place (survivors keep their order), stores the new sizes in
  * *n_verts / *n_faces and synchronises `stream`.
- *   remove_floaters  : drops every connected component (vertices joined by a face) with fewer faces than
- *                      max(1, floor(min_ratio * faces of the largest component)) (MeshLab truncates the product), then
- *                      unreferenced vertices.  Components are joined through shared VERTICES; MeshLab joins faces through
- *                      shared edges, so two parts that touch in a single vertex count as one here.
+ *   remove_floaters  : drops every connected component with fewer faces than max(1, floor(min_ratio * faces of the largest
+ *                      component)) (MeshLab truncates the product), then unreferenced vertices.  Faces are joined through
+ *                      shared EDGES, as MeshLab's face-face adjacency joins them: two parts that touch in a single vertex
+ *                      are two components (r3g_set_option("floater_by_vertex", 1): joined through shared vertices, the
+ *                      behaviour of rounds 1-2).
  *   remove_degenerate: drops faces with a repeated vertex index, then unreferenced vertices.
  *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise quadric-error-metric edge collapse (the algorithm
  *                      class of upstream's MeshLab filter) in rounds of independent collapses: every vertex picks its
@@ -264,7 +265,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * 256-query workgroups make four rounds of the device, otherwise 2 | 2 = four waves of 32 queries | 6 = four waves of 64
  * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
  * LayerNorm / ln_dot row kernels), "ln_fixed" (1: their instantiations with a compile-time row length for C = 1024 / 1536), "attn_pipelined" (0), "attn_ablate"
- * (timing-only masks, results are garbage), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
+ * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
  * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0).  None of them changes a

@@ -20,18 +20,38 @@ def _compact(v, f, keep):
     return v[used], remap[f].astype(np.int32)
 
 
-def remove_floaters(verts, faces, min_ratio=0.005):
+def face_components(faces, n_verts, by_vertex=False):
+    """label per face.  Default: faces joined through shared EDGES (MeshLab's face-face adjacency, which its
+    small-component selection walks): parts that touch in one vertex only are separate.  by_vertex: joined through
+    shared vertices."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import connected_components
+    f = np.asarray(faces, np.int64).reshape(-1, 3)
+    F = len(f)
+    if by_vertex:
+        rows = np.concatenate([f[:, 0], f[:, 0]])
+        cols = np.concatenate([f[:, 1], f[:, 2]])
+        _, label = connected_components(coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(n_verts, n_verts)),
+                                        directed=False)
+        return label[f[:, 0]]
+    e = np.sort(np.stack([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 1).reshape(-1, 2), axis=1)     # the 3F undirected edges
+    fid = np.repeat(np.arange(F), 3)
+    ok = e[:, 0] != e[:, 1]                       # a collapsed side of a degenerate face joins nothing
+    key, fid = e[ok, 0] * np.int64(n_verts) + e[ok, 1], fid[ok]
+    order = np.argsort(key, kind="stable")
+    key, fid = key[order], fid[order]
+    same = key[1:] == key[:-1]                    # consecutive faces around one edge (two, or more if non-manifold)
+    rows, cols = fid[:-1][same], fid[1:][same]
+    _, label = connected_components(coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(F, F)), directed=False)
+    return label
+
+
+def remove_floaters(verts, faces, min_ratio=0.005, by_vertex=False):
     v = np.asarray(verts, np.float32).reshape(-1, 3)
     f = np.asarray(faces, np.int64).reshape(-1, 3)
     if len(v) == 0 or len(f) == 0:
         return v, f.astype(np.int32)
-    n = len(v)
-    rows = np.concatenate([f[:, 0], f[:, 0]])
-    cols = np.concatenate([f[:, 1], f[:, 2]])
-    _, label = connected_components(coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(n, n)), directed=False)
-    fl = label[f[:, 0]]
+    fl = face_components(f, len(v), by_vertex)
     counts = np.bincount(fl)
     keep = counts[fl] >= max(1, int(min_ratio * counts.max()))     # truncation, as MeshLab's (unsigned)(largest * ratio)
     return _compact(v, f, keep)

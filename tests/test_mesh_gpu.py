@@ -68,6 +68,49 @@ def test_soup(nv, nf, seed):
     _same(meshops.cluster_faces(v, f, max(1, nf // 10)), mesh_clean.reduce_faces(hv, hf, max(1, nf // 10)))
 
 
+def _touching_parts():
+    """a big closed blob and a small octahedron that touches it in exactly ONE shared vertex (no shared edge), plus a fan of
+    three faces around one non-manifold edge: the fixture on which shared-vertex and shared-edge connectivity differ"""
+    v, f = _mc_mesh(33, 5, floaters=0)
+    hv, hf = v.cpu().numpy(), f.cpu().numpy().astype(np.int64)
+    n = len(hv)
+    p = hv[7]                                                   # the shared vertex: index 7 of the blob
+    d = 0.02
+    extra = np.array([p + [d, d, 0], p + [d, -d, 0], p + [2 * d, 0, 0], p + [d, 0, d], p + [d, 0, -d]], np.float32)
+    a, b, c, top, bot = n, n + 1, n + 2, n + 3, n + 4            # octahedron: apex 7 .. ring (a, top, b, bot) .. apex c
+    octa = np.array([[7, a, top], [7, top, b], [7, b, bot], [7, bot, a], [c, top, a], [c, b, top], [c, bot, b], [c, a, bot]])
+    m = n + 5                                                   # three faces around the non-manifold edge (m, m+1), far away
+    fan_v = np.array([[5, 5, 5], [5, 5, 6], [6, 5, 5], [5, 6, 5], [4, 4, 5]], np.float32)
+    fan = np.array([[m, m + 1, m + 2], [m, m + 1, m + 3], [m, m + 1, m + 4]])
+    return np.concatenate([hv, extra, fan_v]), np.concatenate([hf, octa, fan]).astype(np.int32), len(hf)
+
+
+def test_floaters_are_joined_through_edges_not_vertices():
+    """MeshLab's small-component filter walks face-face adjacency: a part hanging on the surface by a single vertex is a
+    component of its own (and goes away when it is small); rounds 1-2 joined it to the surface through the vertex."""
+    from oracle import mesh_clean
+    from r3g import ffi, meshops
+    hv, hf, n_blob = _touching_parts()
+    v, f = torch.from_numpy(hv).cuda(), torch.from_numpy(hf).cuda()
+    lab_e = mesh_clean.face_components(hf, len(hv))
+    lab_v = mesh_clean.face_components(hf, len(hv), by_vertex=True)
+    assert len(set(lab_e)) == 3 and len(set(lab_v)) == 2         # blob | octahedron | fan   vs   blob+octahedron | fan
+    assert len(set(lab_e[-3:])) == 1                              # the three faces around the non-manifold edge: one part
+    got = meshops.remove_floaters(v, f, 0.05)
+    want = mesh_clean.remove_floaters(hv, hf, 0.05)
+    _same(got, want)
+    assert len(want[1]) == n_blob                                 # octahedron and fan removed, the blob untouched
+    L = ffi.lib()
+    try:
+        ffi.check(L.r3g_set_option(b"floater_by_vertex", 1))
+        got_v = meshops.remove_floaters(v, f, 0.05)
+    finally:
+        ffi.check(L.r3g_set_option(b"floater_by_vertex", 0))
+    want_v = mesh_clean.remove_floaters(hv, hf, 0.05, by_vertex=True)
+    _same(got_v, want_v)
+    assert len(want_v[1]) == n_blob + 8                           # the octahedron survives when vertices join components
+
+
 @pytest.mark.parametrize("n,budget", [(65, 3000), (129, 40000), (129, 500)])
 def test_cluster_on_mc_mesh(n, budget):
     from oracle import mesh_clean

@@ -608,6 +608,29 @@ def test_fused_and_unfused_paths_agree(tiny):
     assert rel_l2(a, ref) <= TOL["dit_forward_tiny"] and rel_l2(b, ref) <= TOL["dit_forward_tiny"]
 
 
+def test_documented_attention_options_run_the_model(tiny):
+    """r3g_set_option("attn_pipelined", 1) and attn_generation 1 select first-generation kernels that scale the scores
+    themselves: the producers of Q must then leave it plain (attn_q_scale) -- every model attention used to fail with
+    hipErrorInvalidValue under the documented option"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x, t, cond = _inputs(tiny, 14)
+    with torch.no_grad():
+        ref = tiny.oracle.model(x, t, cond)
+    lat0 = x[0]
+    ref_s = tiny.oracle.sample(cond, lat0[None].clone(), 3, 5.0)[0]
+    for name, val, back in ((b"attn_pipelined", 1, 0), (b"attn_generation", 1, 7)):
+        try:
+            ffi.check(L.r3g_set_option(name, val))
+            out = tiny.gpu.dit_forward(x, t, cond).clone()
+            smp = tiny.gpu.flow_sample(lat0.clone(), cond, 3, 5.0).clone()      # the ragged (de-duplicated) launch too
+        finally:
+            ffi.check(L.r3g_set_option(name, back))
+        assert rel_l2(out, ref) <= TOL["dit_forward_tiny"], name
+        assert rel_l2(smp, ref_s) <= TOL["flow_sample"], name
+
+
 def test_cfg_dedup_is_the_same_function(tiny):
     """The unconditional context (zeros) carried as one weighted token must reproduce the plain CFG batch."""
     import torch

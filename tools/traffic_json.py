@@ -77,6 +77,12 @@ def main():
                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 for 16-byte-per-lane loads, "
                                 "weighted by the launch counts of one 50-step object (tools/traffic_json.py)"}
             print("\nfamily %s: %d launches (%d without counters), %.1f MB per launch, %.3f TB per object" % (f, n, miss, b / n / 1e6, b / 1e12))
+    # the build the counters were measured on: bench.py marks the record stale when the library it loads has another digest
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-re-gen_amd", "libr3g.digest")) as f:
+            out["library_digest"] = f.read().strip()
+    except OSError:
+        out["library_digest"] = None
     with open(a.out, "w") as fo:
         json.dump(out, fo, indent=1)
 
