@@ -1182,7 +1182,8 @@ static int g_attn_gen = 7;
 // generation 7 takes the 64-query-per-wave kernel where its 256-query workgroups make at least four full rounds of the
 // 512 slots (the geo decoder's 131072-query passes: +6 %); on the DiT's 4442-query attention the coarser grid costs more
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
-constexpr int kWide6MinItems = 2048;
+static int g_wide6_min_items = 2048;
+void attn_set_wide_min(int items) { if (items > 0) g_wide6_min_items = items; }
 void attn_set_generation(int gen) { if (gen >= 1 && gen <= 7) g_attn_gen = gen; }
 // (the first-generation kernels -- attn_generation 1 and the attn_pipelined option -- scale the scores themselves and
 // reject a pre-scaled Q: producers must then leave q plain)
@@ -1217,7 +1218,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
             return n * p.H;
         };
         int gen = g_attn_gen;
-        if (gen == 7) gen = (g_attn_glds && count(256) >= kWide6MinItems) ? 6 : 2;
+        if (gen == 7) gen = (g_attn_glds && count(256) >= g_wide6_min_items) ? 6 : 2;
         const int qtile = (g_attn_glds && gen >= 4) ? 256 : 128;
         const int items = count(qtile);
         if (g_attn_ablate && gen == 2) {

@@ -1,0 +1,202 @@
+// conv_kernels.hip -- HBM-bound kernels of the SD-2.1-class UNet blocks of the texture stage (gfx950).
+//
+// What diffusers executes as cuDNN conv / GroupNorm / SiLU / GEGLU passes (ResnetBlock2D, Transformer2DModel, Downsample2D),
+// here on rows: an activation is f32 or bf16 [H*W][C] (NHWC -- a pixel's channels are contiguous), so that every linear
+// layer AND every convolution is the MFMA GEMM of gemm.hip over those rows:
+//   * im2col3x3   : bf16 [H][W][C] -> bf16 [Ho*Wo][9 C], column (ky*3 + kx)*C + c, zero padding 1, stride 1 | 2; the 3x3
+//                   convolution is then C_out = A . W^T with W re-laid to [C_out][ky][kx][C_in] (r3g/unet.py).  16 bytes per
+//                   thread, a wave covers 1 KiB of contiguous output.  (An implicit-GEMM staging path that gathers the nine
+//                   shifted rows straight into LDS would save this matrix's round trip through HBM: next step.)
+//   * group_norm  : GroupNorm(32 groups) [+ SiLU] f32 [HW][C] -> bf16, in two launches: per-block partial sums per group
+//                   (fp64 from the group level on, combined in a FIXED order: no float atomics, the result does not depend
+//                   on scheduling), then normalise + affine (+ SiLU).
+//   * geglu       : bf16 [rows][2F] -> bf16 [rows][F] = x[:, :F] * gelu_erf(x[:, F:])   (diffusers GEGLU)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "prof.h"
+
+namespace r3g {
+namespace {
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    const __bf16 h = (__bf16)f;
+    return *reinterpret_cast<const uint16_t*>(&h);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// torch.nn.functional.gelu (exact): erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), as the GEMM epilogue's
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int stride,
+                                                        int Ho, int Wo, uint16_t* __restrict__ out) {
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)Ho * Wo * 9 * c8n;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % c8n);
+    const int64_t r = i / c8n;
+    const int tap = (int)(r % 9);
+    const int64_t m = r / 9;
+    const int oy = (int)(m / Wo), ox = (int)(m % Wo);
+    const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + ((int64_t)iy * W + ix) * C + c8 * 8);
+    *reinterpret_cast<uint4*>(out + m * (9 * (int64_t)C) + (int64_t)tap * C + c8 * 8) = v;
+}
+
+// ---- GroupNorm, pass 1: block b sums rows [b*rpb, (b+1)*rpb) per channel (thread t owns channels t, t + 256, ...), folds
+// the channels of a group in LDS and writes (sum, sum of squares) per group as fp64 to partial[b][g][2]
+constexpr int GN_MAX_CPT = 8;   // channels per thread: C <= 2048
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int C, int groups, int rpb,
+                                                         double* __restrict__ partial) {
+    __shared__ float s_sum[2048], s_sq[2048];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    float a[GN_MAX_CPT], q[GN_MAX_CPT];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CPT; ++k) { a[k] = 0.f; q[k] = 0.f; }
+    for (int r = r0; r < r1; ++r) {
+        const float* row = x + (int64_t)r * C;
+#pragma unroll
+        for (int k = 0; k < GN_MAX_CPT; ++k) {
+            const int c = t + k * 256;
+            if (c < C) { const float v = row[c]; a[k] += v; q[k] += v * v; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CPT; ++k) {
+        const int c = t + k * 256;
+        if (c < C) { s_sum[c] = a[k]; s_sq[c] = q[k]; }
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int g = t; g < groups; g += 256) {
+        double s = 0.0, ss = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)s_sum[c]; ss += (double)s_sq[c]; }
+        partial[((int64_t)blockIdx.x * groups + g) * 2] = s;
+        partial[((int64_t)blockIdx.x * groups + g) * 2 + 1] = ss;
+    }
+}
+
+// ---- pass 2: every block first combines the partials of all groups (block order 0, 1, 2, ...: the same sum in every
+// block), then normalises its rows: y = ((x - mean) * rstd * gamma + beta) [-> SiLU] -> bf16, 4 channels per thread
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int rows, int C, int groups, int nblk,
+                                                       const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int do_silu, int rpb,
+                                                       uint16_t* __restrict__ y) {
+    __shared__ float s_mean[256], s_rstd[256];
+    const int t = threadIdx.x;
+    const int cpg = C / groups;
+    for (int g = t; g < groups; g += 256) {
+        double s = 0.0, ss = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += partial[((int64_t)b * groups + g) * 2];
+            ss += partial[((int64_t)b * groups + g) * 2 + 1];
+        }
+        const double n = (double)rows * cpg;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;      // biased, as torch.nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    const int c4n = C >> 2;
+    for (int64_t i = (int64_t)r0 * c4n + t; i < (int64_t)r1 * c4n; i += 256) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t r = i / c4n;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+        const float in[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gm.x, gm.y, gm.z, gm.w}, bw[4] = {bt.x, bt.y, bt.z, bt.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            const float z = (in[e] - s_mean[g]) * s_rstd[g] * gw[e] + bw[e];
+            o[e] = do_silu ? silu(z) : z;
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+        *reinterpret_cast<uint2*>(y + r * C + c) = pk;
+    }
+}
+
+__global__ __launch_bounds__(256) void geglu_kernel(const uint16_t* __restrict__ in, int64_t ldi, uint16_t* __restrict__ out,
+                                                    int64_t ldo, int rows, int F) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= (int64_t)rows * F) return;
+    const int r = (int)(i / F), c = (int)(i % F);  // F % 8 == 0
+    const uint4 a = *reinterpret_cast<const uint4*>(in + (int64_t)r * ldi + c);
+    const uint4 g = *reinterpret_cast<const uint4*>(in + (int64_t)r * ldi + F + c);
+    const uint32_t au[4] = {a.x, a.y, a.z, a.w}, gu[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a0 = __uint_as_float(au[e] << 16), a1 = __uint_as_float(au[e] & 0xFFFF0000u);
+        const float g0 = __uint_as_float(gu[e] << 16), g1 = __uint_as_float(gu[e] & 0xFFFF0000u);
+        o[e] = (uint32_t)f2bf(a0 * gelu_erf(g0)) | ((uint32_t)f2bf(a1 * gelu_erf(g1)) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
+}
+
+}  // namespace
+
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, uint16_t* out, hipStream_t s) {
+    if (C % 8 || (stride != 1 && stride != 2) || H < 1 || W < 1) return hipErrorInvalidValue;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int64_t total = (int64_t)Ho * Wo * 9 * (C / 8);
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, H, W, C, stride, Ho, Wo, out);
+    return hipGetLastError();
+}
+
+int group_norm_blocks(int rows) {
+    int nblk = (rows + 15) / 16;          // at least 16 rows per block, at most 256 blocks
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    return nblk;
+}
+
+hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s) {
+    if (C % 4 || groups < 1 || groups > 256 || C % groups || C > 256 * GN_MAX_CPT || rows < 1) return hipErrorInvalidValue;
+    const int nblk = group_norm_blocks(rows);
+    const int rpb = (rows + nblk - 1) / nblk;
+    ProfScope prof_scope_(PC_LAYERNORM, 0.0, s);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C, groups, rpb, partial);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C, groups, nblk, (const double*)partial, gamma,
+                       beta, eps, do_silu, rpb, y);
+    return hipGetLastError();
+}
+
+hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s) {
+    if (F % 8 || (ldi & 7) || (ldo & 7)) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(geglu_kernel, dim3(blocks_for((int64_t)rows * F / 8, 256)), dim3(256), 0, s, in, ldi, out, ldo, rows, F);
+    return hipGetLastError();
+}
+
+hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(vec_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a, b, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace r3g

@@ -364,6 +364,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     if constexpr (EPI == EPI_RESID_BF16) {
         // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
         uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
+        const uint16_t* XR = p.resid_src ? p.resid_src + (int64_t)batch * p.strideC : X;   // where the old values come from
         f32x4 bj[4], gj[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -375,7 +376,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (gate) gj[j] = *reinterpret_cast<const f32x4*>(gate + nbc);
         }
         const bool wide = lds_wave != nullptr && PI >= 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0 &&
-                          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+                          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(XR) & 15) == 0;
         if (wide) {
             // passes of RP rows x 64 columns of fp32 through the wave's scratch (256-byte rows, 16-byte chunks swizzled by
             // the row); the read side owns 8 consecutive columns of a row: one 16-byte load of the old values, one
@@ -392,7 +393,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
                     const int mc = m < p.M ? m : p.M - 1;
                     const int nc = n < p.N ? n : p.N - 8;
-                    old[t] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * p.ldc + nc);
+                    old[t] = *reinterpret_cast<const uint4*>(XR + (int64_t)mc * p.ldc + nc);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -432,7 +433,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             for (int i = 0; i < MI; ++i) {
                 const int n = ncol + j * 16, m = mrow + i * 16;
                 const int nc = n < p.N ? n : p.N - 4, mc = m < p.M ? m : p.M - 1;
-                old[i] = *reinterpret_cast<const uint2*>(X + (int64_t)mc * p.ldc + nc);
+                old[i] = *reinterpret_cast<const uint2*>(XR + (int64_t)mc * p.ldc + nc);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {

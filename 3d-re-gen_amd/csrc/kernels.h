@@ -66,6 +66,7 @@ struct GemmArgs {
     int64_t ldc, strideC;
     const float* gate;  // [batch][N] (strideGate, may be 0) or null
     int64_t strideGate;
+    const uint16_t* resid_src;   // EPI_RESID_BF16: the old values are read from here (same ldc / strideC) instead of from C; null: C
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
     int batch;          // filled in by gemm_launch
@@ -124,6 +125,7 @@ struct AttnArgs {
 hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
 // factor the producers of Q fold into it for the current attention kernel: scale * log2(e) (generation 2), or 1
 float attn_q_scale(float scale);
+void attn_set_wide_min(int items);     // generation 7: 256-query workgroups (generation 6) from this many work items on (default 2048)
 void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
 void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave
 void ln_set_fixed_count(bool on);     // 1 (default): compile-time element counts for C = 1024 / 1536
@@ -199,6 +201,17 @@ hipError_t quant_fp8_rows_launch(const uint16_t* x, int64_t ldx, int rows, int K
                                  hipStream_t s);
 hipError_t gemm_fp8_launch(const GemmArgs& p, const float* scale_a, const float* scale_w, hipStream_t s);
 hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStream_t s);
+
+// ------------------------------------------------------------------ UNet blocks of the texture stage (conv_kernels.hip)
+// bf16 [H][W][C] -> bf16 [Ho*Wo][9 C] (column (ky*3 + kx)*C + c; zero padding 1; stride 1 | 2; C % 8 == 0)
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, uint16_t* out, hipStream_t s);
+// GroupNorm (+ SiLU) of f32 rows [rows][C] -> bf16; partial: workspace of group_norm_blocks(rows) * groups * 2 doubles
+int group_norm_blocks(int rows);
+hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s);
+// out(bf16)[r][c] = in[r][c] * gelu_erf(in[r][F + c])   (diffusers GEGLU)
+hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
+hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);
 
 }  // namespace r3g
 #endif

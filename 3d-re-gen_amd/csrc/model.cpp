@@ -15,6 +15,7 @@
 // The residual stream is fp32 in HBM; GEMM operands are bf16; accumulation fp32.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -56,6 +57,7 @@ static int g_geo_fp8 = 0;   // BASELINE.json configs[3]: geo decoder GEMMs on fp
 constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP hidden: |GELU| up to 28 representable
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
+static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
 
 struct Model {
@@ -104,6 +106,20 @@ struct Model {
         int *seg_txt = nullptr, *seg_all = nullptr;
         std::vector<int> h_seg_txt, h_seg_all;
     } db;
+    // Query-side cache of the geo decoder (option geo_q_cache).  Everything a grid point contributes BEFORE it meets an
+    // object's latents -- Fourier features, query_proj (the start of its residual stream), ln_1, c_q, q-norm, the scaled Q rows
+    // -- is a function of the point's index and the WEIGHTS only, identical for every object.  With 288 GB of HBM the two
+    // results (x0 and Q, bf16, 2 x 34.8 GB at 257^3) stay resident: a pass that has been through once reads them instead of
+    // recomputing them (bit-identical by construction; -4 launches and ~36 TFLOP per object).  Built lazily pass by pass;
+    // dropped when a weight is (re)registered, the grid changes, or the memory is not there (513^3 would need 557 GB).
+    struct GeoCache {
+        int R = -1;
+        double bound = 0.0;
+        int64_t passes = 0;
+        uint16_t *x0 = nullptr, *Q = nullptr;   // [passes][qc][W] each
+        std::vector<char> built;
+        bool refused = false;                   // allocation failed for this (R, bound): do not try again
+    } gq;
     std::string err;
 
     const Tensor* find(const std::string& name) const {
@@ -231,9 +247,10 @@ static int layernorm(const float* x, int64_t ldx, int64_t xbs, uint16_t* y, int6
 }
 
 static int attention(const Model& m, int B, int heads, int Lq, int Lq_pad, int Lk, int Lk_pad, uint16_t* O, int64_t ldo,
-                     int64_t strideO, const uint16_t* Kp, const uint16_t* Vtp, bool shared_kv, hipStream_t s) {
+                     int64_t strideO, const uint16_t* Kp, const uint16_t* Vtp, bool shared_kv, hipStream_t s,
+                     const uint16_t* Qp = nullptr) {
     AttnArgs p{};
-    p.Q = m.Q; p.K = Kp; p.Vt = Vtp; p.O = O; p.ldo = ldo; p.strideO = strideO;
+    p.Q = Qp ? Qp : m.Q; p.K = Kp; p.Vt = Vtp; p.O = O; p.ldo = ldo; p.strideO = strideO;
     p.B = B; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
     p.kv_batch_stride_zero = shared_kv ? 1 : 0;
     p.scale = 0.125f;
@@ -772,18 +789,50 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
     const float ob = obi->second;
     const bool qkn = c.vae_qk_norm && c.vae_ln_post;
     const int Lkp = (int)rup(Nl, 64);
+    // residual stream of the decoder block: fp32 (round 1) or, by default, bf16 -- the reference keeps it in fp16; it is
+    // read / written 7 times per point, 0.9 TB per object in fp32.  The bf16 stream lives in the same buffer (m.f32a).
+    const int xb = g_geo_resid_bf16 && W % 256 == 0 ? 1 : 0;
+    const int epi_x0 = xb ? EPI_BF16 : EPI_F32, epi_res = xb ? EPI_RESID_BF16 : EPI_RESID_F32;
+    // fp8 mode (option geo_fp8, BASELINE.json configs[3]): LayerNorm writes e4m3 + row scales, c_q / c_fc / mlp.c_proj run
+    // on fp8 operands; the attention, its output projection and the residual stream stay bf16
+    const bool f8 = g_geo_fp8 != 0 && xb && W % 256 == 0 && lfc.N % 256 == 0;
+    const bool f8q = f8 && g_geo_fp8 != 2, f8m = f8 && g_geo_fp8 != 3;
+    // the query-side cache (Model::GeoCache): bf16 stream, bf16 c_q, and room for 2 x passes x qc x W bf16 in HBM
+    Model::GeoCache& gq = m.gq;
+    const int64_t passes_all = (total + m.qc - 1) / m.qc;
+    bool use_cache = g_geo_q_cache && xb && !f8q;
+    if (use_cache && (gq.R != R || gq.bound != bound)) {
+        if (gq.x0) { R3G_TRY(hipStreamSynchronize(s)); (void)hipFree(gq.x0); gq.x0 = nullptr; gq.Q = nullptr; }
+        gq.R = R; gq.bound = bound; gq.passes = 0; gq.built.clear(); gq.refused = false;
+    }
+    // (no allocation for a call that contains no canonical pass, e.g. a test's 3 000-point slice of the grid)
+    const bool has_canon = start % m.qc == 0 && count >= std::min<int64_t>(m.qc, total - start);
+    if (use_cache && !gq.x0 && !gq.refused && has_canon) {
+        const size_t need = (size_t)passes_all * m.qc * W * 2 * 2;
+        size_t free_b = 0, total_b = 0;
+        hipError_t e = hipMemGetInfo(&free_b, &total_b);
+        if (e != hipSuccess || free_b < need + ((size_t)16 << 30) || hipMalloc((void**)&gq.x0, need) != hipSuccess) {
+            (void)hipGetLastError();
+            gq.x0 = nullptr;
+            gq.refused = true;            // e.g. 513^3: 557 GB -- every pass is recomputed, as before
+        } else {
+            gq.Q = gq.x0 + (int64_t)passes_all * m.qc * W;
+            gq.passes = passes_all;
+            gq.built.assign((size_t)passes_all, 0);
+        }
+    }
+    use_cache = use_cache && gq.x0 != nullptr;
     for (int64_t off = 0; off < count; off += m.qc) {
         const int n = (int)std::min<int64_t>(m.qc, count - off);
         const int npad = (int)rup(n, 128);
-        R3G_TRY(fourier_grid_launch(m.inb, start + off, npad, R, bound, c.vae_num_freqs, c.vae_include_pi, s));
-        // residual stream of the decoder block: fp32 (round 1) or, by default, bf16 -- the reference keeps it in fp16; it is
-        // read / written 7 times per point, 0.9 TB per object in fp32.  The bf16 stream lives in the same buffer (m.f32a).
-        const int xb = g_geo_resid_bf16 && W % 256 == 0 ? 1 : 0;
-        const int epi_x0 = xb ? EPI_BF16 : EPI_F32, epi_res = xb ? EPI_RESID_BF16 : EPI_RESID_F32;
-        // fp8 mode (option geo_fp8, BASELINE.json configs[3]): LayerNorm writes e4m3 + row scales, c_q / c_fc / mlp.c_proj run
-        // on fp8 operands; the attention, its output projection and the residual stream stay bf16
-        const bool f8 = g_geo_fp8 != 0 && xb && W % 256 == 0 && lfc.N % 256 == 0;
-        const bool f8q = f8 && g_geo_fp8 != 2, f8m = f8 && g_geo_fp8 != 3;
+        // a pass is served from / stored into the cache when it is one of the grid's canonical passes: it starts at a
+        // multiple of the pass size and covers the pass completely (sub-range queries are computed the old way)
+        const int64_t p0 = start + off;
+        const int64_t pidx = p0 / m.qc;
+        const bool canon = use_cache && p0 % m.qc == 0 && n == (int)std::min<int64_t>(m.qc, total - p0);
+        const bool hit = canon && gq.built[(size_t)pidx];
+        uint16_t* x0 = canon ? gq.x0 + pidx * (int64_t)m.qc * W : reinterpret_cast<uint16_t*>(m.f32a);
+        uint16_t* Qp = canon ? gq.Q + pidx * (int64_t)m.qc * W : m.Q;
         uint8_t* xn8 = reinterpret_cast<uint8_t*>(m.xn);
         uint8_t* hid8 = reinterpret_cast<uint8_t*>(m.hid);
         if (f8 && !m.fp8_sa) {
@@ -791,23 +840,33 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_TRY(hipMalloc((void**)&m.fp8_sconst, 4 * (size_t)m.qc));
             R3G_RC(fill_f32(m.fp8_sconst, m.qc, kGeoHiddenScale, s));
         }
-        R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, m.f32a, W, 0, n, 64, epi_x0, nullptr, 0, 1, s));
-        if (f8q) R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l1w, l1b, 1e-6f, s, xb));
-        else R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
-        QkvSplitArgs q{};
-        q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
-        q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
-        q.Q = m.Q; q.K = nullptr; q.Vt = nullptr; q.Lq_pad = npad; q.Lk_pad = 0; q.dst_row0 = 0;
-        q.B = 1; q.H = heads; q.L = n; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
-        q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
-        if (qkn) {
-            R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
-            R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
+        if (!hit) {
+            R3G_TRY(fourier_grid_launch(m.inb, p0, npad, R, bound, c.vae_num_freqs, c.vae_include_pi, s));
+            R3G_RC(gemm(m.inb, 64, 0, lq, 0, W, xb ? (void*)x0 : (void*)m.f32a, W, 0, n, 64, epi_x0, nullptr, 0, 1, s));
+            const float* xin = xb ? reinterpret_cast<const float*>(x0) : m.f32a;
+            if (f8q) R3G_RC(layernorm_fp8(xin, W, xn8, W, m.fp8_sa, n, W, l1w, l1b, 1e-6f, s, xb));
+            else R3G_RC(layernorm(xin, W, 0, m.xn, W, 0, n, 1, W, l1w, l1b, nullptr, nullptr, 0, 1e-6f, s, xb));
+            QkvSplitArgs q{};
+            q.src = m.qkv; q.ld = W; q.src_batch_stride = 0;
+            q.q_off = 0; q.k_off = -1; q.v_off = -1; q.head_stride = 64;
+            q.Q = Qp; q.K = nullptr; q.Vt = nullptr; q.Lq_pad = npad; q.Lk_pad = 0; q.dst_row0 = 0;
+            q.B = 1; q.H = heads; q.L = n; q.eps = 1e-6f; q.q_scale = attn_q_scale(0.125f);
+            q.norm = qkn ? QKN_LAYERNORM : QKN_NONE;
+            if (qkn) {
+                R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.weight", 64, &q.qw));
+                R3G_RC(get_vec(m, g + ".cross_attn_decoder.attn.attention.q_norm.bias", 64, &q.qb));
+            }
+            if (f8q) R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lcq, nullptr, 0, n, EPI_QKV, &q, QKV_Q_ONLY, s));
+            else R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
+            if (canon) gq.built[(size_t)pidx] = 1;
         }
-        if (f8q) R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lcq, nullptr, 0, n, EPI_QKV, &q, QKV_Q_ONLY, s));
-        else R3G_RC(gemm_qkv(m, m.xn, W, 0, lcq, 0, W, n, W, 1, q, QKV_Q_ONLY, s));
-        R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s));
-        R3G_RC(gemm(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0, 1, s));
+        R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s, Qp));
+        {   // x1 = x0 + c_proj(attention): the old values come from the cached x0 where there is one
+            GemmArgs pr = gemm_args(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0);
+            if (canon) pr.resid_src = x0;
+            hipError_t e = gemm_launch(pr, 1, s);
+            if (e != hipSuccess) return hip_fail(e, "gemm_launch(geo c_proj)");
+        }
         if (f8m) {
             R3G_RC(layernorm_fp8(m.f32a, W, xn8, W, m.fp8_sa, n, W, l3w, l3b, 1e-6f, s, xb));
             R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lfc, hid8, lfc.N, n, EPI_FP8_GELU_ERF, nullptr, 0, s));
@@ -887,6 +946,7 @@ static void model_free(Model* m) {
     if (m->fp8_sa) (void)hipFree(m->fp8_sa);
     if (m->fp8_sconst) (void)hipFree(m->fp8_sconst);
     if (m->db.base) (void)hipFree(m->db.base);
+    if (m->gq.x0) (void)hipFree(m->gq.x0);
     delete m;
 }
 
@@ -974,6 +1034,7 @@ int r3g_model_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int 
     if (!name || !d_ptr || (dtype != 0 && dtype != 1) || rows <= 0 || cols <= 0)
         return fail(R3G_ERR_INVALID, "r3g_model_set_tensor: bad argument for '%s'", name ? name : "?");
     m->w[name] = Tensor{d_ptr, dtype, rows, cols};
+    if (!m->gq.built.empty()) std::fill(m->gq.built.begin(), m->gq.built.end(), 0);   // the cached query side belongs to the old weights
     return R3G_OK;
 }
 
@@ -1166,6 +1227,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "skip_zero_step")) g_skip_zero_step = value != 0;
+    else if (!strcmp(name, "geo_q_cache")) g_geo_q_cache = value != 0;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
@@ -1181,6 +1243,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
+    else if (!strcmp(name, "attn_wide_min")) attn_set_wide_min(value);
     else if (!strcmp(name, "ln_rows")) ln_set_rows_per_wave(value);
     else if (!strcmp(name, "ln_fixed")) ln_set_fixed_count(value != 0);
     else if (!strcmp(name, "floater_by_vertex")) mesh_set_floater_by_vertex(value != 0);

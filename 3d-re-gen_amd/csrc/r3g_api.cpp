@@ -88,6 +88,7 @@ void r3g_destroy(r3g_ctx* ctx) {
     if (c->tex_ws) (void)hipFree(c->tex_ws);
     if (c->h_small) (void)hipHostFree(c->h_small);
     c->release_model();
+    c->release_unet();
     delete c;
 }
 

@@ -35,6 +35,8 @@ struct Ctx {
     int reserve(char** buf, size_t* have, size_t need, const char* what);
     void* model = nullptr;  // r3g::Model (model.cpp)
     void release_model();
+    void* unet = nullptr;   // r3g::Unet (unet.cpp)
+    void release_unet();
 };
 
 }  // namespace r3g

@@ -1,0 +1,384 @@
+// unet.cpp -- host-side orchestration of SD-2.1-class UNet blocks on one MI355X (compiled by hipcc).
+//
+// SURVEY.md 8(f) rank 3, first slice: the building blocks of the two diffusion UNets behind upstream's
+// `Hunyuan3DPaintPipeline.__call__` (reference call site src/2d_to_3d_models/run.py:97; built at :126-128) -- diffusers
+// ResnetBlock2D, Transformer2DModel (use_linear_projection) with one BasicTransformerBlock (self-attention, cross-attention
+// over the text / image context, GEGLU feed-forward), Downsample2D, and their compositions CrossAttnDownBlock2D and
+// UNetMidBlock2DCrossAttn.  Weights are registered under diffusers' state-dict names ("down_blocks.0.resnets.0.conv1.weight").
+//
+// Activations are rows: f32 [H*W][C] (the hidden state; a pixel's channels contiguous), GEMM operands bf16.  Every
+// convolution is im2col3x3 (conv_kernels.hip) + the MFMA GEMM of gemm.hip with its fused epilogues (bias, fp32 residual
+// add); a 1x1 convolution is the GEMM itself.  Attention is attn.hip's flash kernel (head dim 64: SD 2.x's heads).
+// What is NOT here yet: conv_in / conv_out, the up blocks, the time-embedding MLP, the VAE, schedulers, and upstream's
+// multiview / reference attention extensions -- the texture stage keeps reporting its `texture_source` (stage/run.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/r3g.h"
+#include "kernels.h"
+#include "prof.h"
+#include "r3g_ctx.h"
+
+namespace r3g {
+
+struct UTensor {
+    const void* p;
+    int dtype;  // 0 f32, 1 bf16
+    int64_t rows, cols;
+};
+
+struct Unet {
+    r3g_unet_config c{};
+    std::unordered_map<std::string, UTensor> w;
+    char* arena = nullptr;
+    // activation buffers (sized for max_hw rows x max_channels)
+    float *h = nullptr, *t1 = nullptr;     // transformer-level hidden state, resnet intermediate
+    uint16_t *xn = nullptr;                // normalised / cast operand [hw][C]
+    uint16_t *col = nullptr;               // im2col matrix [hw][9 C]
+    uint16_t *Q = nullptr, *K = nullptr, *Vt = nullptr, *att = nullptr;
+    uint16_t *ff = nullptr, *ff2 = nullptr;   // [hw][8 C], [hw][4 C]
+    uint16_t *ctxK = nullptr, *ctxVt = nullptr;
+    float *vec = nullptr;                  // [4][max_channels] small vectors
+    double* gn_partial = nullptr;
+};
+
+#define U_TRY(expr)                                            \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);    \
+    } while (0)
+#define U_RC(expr)                  \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__) return rc__;      \
+    } while (0)
+
+static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct ULin {
+    const uint16_t* w = nullptr;
+    const float* b = nullptr;
+    int N = 0, K = 0;
+};
+
+static int u_lin(const Unet& u, const std::string& base, bool need_bias, int N, int K, ULin* out) {
+    auto it = u.w.find(base + ".weight");
+    if (it == u.w.end() || it->second.dtype != 1) return fail(R3G_ERR_STATE, "unet: missing bf16 weight '%s.weight'", base.c_str());
+    if (it->second.rows != N || it->second.cols != K)
+        return fail(R3G_ERR_INVALID, "unet: '%s.weight' is [%lld][%lld], expected [%d][%d]", base.c_str(),
+                    (long long)it->second.rows, (long long)it->second.cols, N, K);
+    out->w = (const uint16_t*)it->second.p;
+    out->N = N; out->K = K;
+    auto ib = u.w.find(base + ".bias");
+    out->b = nullptr;
+    if (ib != u.w.end()) {
+        if (ib->second.dtype != 0 || ib->second.rows * ib->second.cols != N)
+            return fail(R3G_ERR_INVALID, "unet: '%s.bias' must be f32 [%d]", base.c_str(), N);
+        out->b = (const float*)ib->second.p;
+    } else if (need_bias) {
+        return fail(R3G_ERR_STATE, "unet: missing '%s.bias'", base.c_str());
+    }
+    return R3G_OK;
+}
+
+static int u_vec(const Unet& u, const std::string& name, int n, const float** out) {
+    auto it = u.w.find(name);
+    if (it == u.w.end() || it->second.dtype != 0) return fail(R3G_ERR_STATE, "unet: missing f32 tensor '%s'", name.c_str());
+    if (it->second.rows * it->second.cols != n) return fail(R3G_ERR_INVALID, "unet: '%s' has the wrong size", name.c_str());
+    *out = (const float*)it->second.p;
+    return R3G_OK;
+}
+
+static int u_gemm(const uint16_t* A, int64_t lda, const ULin& l, const float* bias, void* C, int64_t ldc, int M, int epi,
+                  hipStream_t s) {
+    GemmArgs p{};
+    p.A = A; p.lda = lda; p.W = l.w; p.ldw = l.K; p.bias = bias; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = l.N; p.K = l.K; p.epi = epi;
+    hipError_t e = gemm_launch(p, 1, s);
+    if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet)");
+    return R3G_OK;
+}
+
+static int u_check_shape(const Unet& u, int H, int W, int C, const char* what) {
+    if (H < 1 || W < 1 || (int64_t)H * W > u.c.max_hw || C > u.c.max_channels || C % 64 || C % u.c.groups)
+        return fail(R3G_ERR_INVALID, "%s: %d x %d x %d does not fit the unet arena (max_hw %d, max_channels %d; C %% 64 == 0)", what,
+                    H, W, C, u.c.max_hw, u.c.max_channels);
+    return R3G_OK;
+}
+
+// conv 3x3 (pad 1) of bf16 rows src [H*W][Cin] -> epilogue(dst [Ho*Wo][Cout])
+static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int stride, const ULin& l, const float* bias, void* dst,
+                     int epi, hipStream_t s) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    U_TRY(im2col3x3_launch(src, H, W, Cin, stride, u.col, s));
+    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, Ho * Wo, epi, s);
+}
+
+// diffusers ResnetBlock2D.forward: out = shortcut(x) + conv2(silu(norm2(conv1(silu(norm1(x))) + time_emb_proj(silu(temb)))))
+static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, int W, int Cin, int Cout, const float* temb,
+                       float* out, hipStream_t s) {
+    U_RC(u_check_shape(u, H, W, Cin, "r3g_unet_resnet"));
+    U_RC(u_check_shape(u, H, W, Cout, "r3g_unet_resnet"));
+    const int hw = H * W, G = u.c.groups;
+    const float *g1, *b1, *g2, *b2;
+    U_RC(u_vec(u, pre + ".norm1.weight", Cin, &g1));
+    U_RC(u_vec(u, pre + ".norm1.bias", Cin, &b1));
+    U_RC(u_vec(u, pre + ".norm2.weight", Cout, &g2));
+    U_RC(u_vec(u, pre + ".norm2.bias", Cout, &b2));
+    ULin c1, c2, tp;
+    U_RC(u_lin(u, pre + ".conv1", true, Cout, 9 * Cin, &c1));
+    U_RC(u_lin(u, pre + ".conv2", true, Cout, 9 * Cout, &c2));
+    U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
+    // per-channel constant of conv1's epilogue: conv1.bias + time_emb_proj(silu(temb))
+    float* tb = u.vec;
+    float* cb = u.vec + u.c.max_channels;
+    U_TRY(gemv_launch(temb, 1, u.c.temb_dim, tp.w, tp.K, tp.b, tb, Cout, 1, 0, s));
+    U_TRY(vec_add_launch(c1.b, tb, cb, Cout, s));
+    U_TRY(group_norm_launch(x, hw, Cin, G, g1, b1, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
+    U_RC(u_conv3x3(u, u.xn, H, W, Cin, 1, c1, cb, u.t1, EPI_F32, s));
+    U_TRY(group_norm_launch(u.t1, hw, Cout, G, g2, b2, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
+    // the residual: x itself, or conv_shortcut (1x1) of x, lands in `out` first; conv2's epilogue adds onto it
+    if (Cin != Cout || u.w.count(pre + ".conv_shortcut.weight")) {
+        ULin sc;
+        U_RC(u_lin(u, pre + ".conv_shortcut", true, Cout, Cin, &sc));
+        uint16_t* xb = u.ff;       // bf16 copy of x (free here)
+        U_TRY(f32_to_bf16_launch(x, xb, (int64_t)hw * Cin, s));
+        U_RC(u_gemm(xb, Cin, sc, sc.b, out, Cout, hw, EPI_F32, s));
+    } else if (out != x) {
+        U_TRY(hipMemcpyAsync(out, x, (size_t)hw * Cout * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return u_conv3x3(u, u.xn, H, W, Cout, 1, c2, c2.b, out, EPI_RESID_F32, s);
+}
+
+static int u_layernorm(const float* x, uint16_t* y, int rows, int C, const float* w, const float* b, float eps, hipStream_t s) {
+    LnArgs p{};
+    p.x = x; p.ldx = C; p.y = y; p.ldy = C; p.w = w; p.b = b;
+    p.rows = rows; p.C = C; p.rows_per_batch = rows; p.eps = eps;
+    hipError_t e = layernorm_launch(p, s);
+    if (e != hipSuccess) return hip_fail(e, "layernorm_launch(unet)");
+    return R3G_OK;
+}
+
+static int u_attention(Unet& u, int heads, int Lq, int Lq_pad, int Lk, int Lk_pad, const uint16_t* K, const uint16_t* Vt, int C,
+                       hipStream_t s) {
+    AttnArgs p{};
+    p.Q = u.Q; p.K = K; p.Vt = Vt; p.O = u.att; p.ldo = C; p.strideO = 0;
+    p.B = 1; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
+    p.scale = 0.125f;
+    p.q_prescaled = attn_q_scale(0.125f) != 1.0f;
+    hipError_t e = attention_launch(p, s);
+    if (e != hipSuccess) return hip_fail(e, "attention_launch(unet)");
+    return R3G_OK;
+}
+
+static GemmArgs u_qkv_args(const uint16_t* A, int64_t lda, const ULin& l, int M, int heads, int layout, uint16_t* Q, uint16_t* K,
+                           uint16_t* Vt, int Lq_pad, int Lk_pad) {
+    GemmArgs p{};
+    p.A = A; p.lda = lda; p.W = l.w; p.ldw = l.K; p.bias = l.b;
+    p.M = M; p.N = l.N; p.K = l.K; p.epi = EPI_QKV;
+    p.qkv.Q = Q; p.qkv.K = K; p.qkv.Vt = Vt; p.qkv.Lq_pad = Lq_pad; p.qkv.Lk_pad = Lk_pad;
+    p.qkv.heads = heads; p.qkv.layout = layout; p.qkv.norm = QKN_NONE; p.qkv.q_scale = attn_q_scale(0.125f);
+    return p;
+}
+
+// diffusers Transformer2DModel (use_linear_projection, one BasicTransformerBlock), in place on x f32 [H*W][C].
+// Fused projection weights are registered by r3g/unet.py (pure re-layouts): attn1.to_qkv = cat(to_q, to_k, to_v) rows,
+// attn2.to_kv = per head (k rows, v rows) of to_k / to_v.
+static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, int W, int C, const uint16_t* ctx, int tokens,
+                            hipStream_t s) {
+    U_RC(u_check_shape(u, H, W, C, "r3g_unet_transformer"));
+    if (tokens < 1 || tokens > u.c.ctx_tokens) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: %d context tokens (max %d)", tokens, u.c.ctx_tokens);
+    const int hw = H * W, heads = C / 64, Lp = (int)rup(hw, 128), Lkp = (int)rup(tokens, 64);
+    const std::string blk = pre + ".transformer_blocks.0";
+    const float *gw, *gb, *w1, *b1, *w2, *b2, *w3, *b3;
+    U_RC(u_vec(u, pre + ".norm.weight", C, &gw));
+    U_RC(u_vec(u, pre + ".norm.bias", C, &gb));
+    U_RC(u_vec(u, blk + ".norm1.weight", C, &w1));
+    U_RC(u_vec(u, blk + ".norm1.bias", C, &b1));
+    U_RC(u_vec(u, blk + ".norm2.weight", C, &w2));
+    U_RC(u_vec(u, blk + ".norm2.bias", C, &b2));
+    U_RC(u_vec(u, blk + ".norm3.weight", C, &w3));
+    U_RC(u_vec(u, blk + ".norm3.bias", C, &b3));
+    ULin pin, pout, qkv, o1, q2, kv2, o2, f0, f2;
+    U_RC(u_lin(u, pre + ".proj_in", true, C, C, &pin));
+    U_RC(u_lin(u, pre + ".proj_out", true, C, C, &pout));
+    U_RC(u_lin(u, blk + ".attn1.to_qkv", false, 3 * C, C, &qkv));
+    U_RC(u_lin(u, blk + ".attn1.to_out.0", true, C, C, &o1));
+    U_RC(u_lin(u, blk + ".attn2.to_q", false, C, C, &q2));
+    U_RC(u_lin(u, blk + ".attn2.to_kv", false, 2 * C, u.c.ctx_dim, &kv2));
+    U_RC(u_lin(u, blk + ".attn2.to_out.0", true, C, C, &o2));
+    U_RC(u_lin(u, blk + ".ff.net.0.proj", true, 8 * C, C, &f0));
+    U_RC(u_lin(u, blk + ".ff.net.2", true, C, 4 * C, &f2));
+    // norm (GroupNorm, no activation) -> proj_in -> hidden state h
+    U_TRY(group_norm_launch(x, hw, C, u.c.groups, gw, gb, 1e-6f, 0, u.xn, u.gn_partial, s));
+    U_RC(u_gemm(u.xn, C, pin, pin.b, u.h, C, hw, EPI_F32, s));
+    // self-attention
+    U_RC(u_layernorm(u.h, u.xn, hw, C, w1, b1, 1e-5f, s));
+    {
+        const GemmArgs p = u_qkv_args(u.xn, C, qkv, hw, heads, QKV_KHD, u.Q, u.K, u.Vt, Lp, Lp);
+        hipError_t e = gemm_launch(p, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet qkv)");
+    }
+    U_RC(u_attention(u, heads, hw, Lp, hw, Lp, u.K, u.Vt, C, s));
+    U_RC(u_gemm(u.att, C, o1, o1.b, u.h, C, hw, EPI_RESID_F32, s));
+    // cross-attention over the context tokens
+    U_RC(u_layernorm(u.h, u.xn, hw, C, w2, b2, 1e-5f, s));
+    {
+        const GemmArgs pq = u_qkv_args(u.xn, C, q2, hw, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lp, 0);
+        hipError_t e = gemm_launch(pq, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet q)");
+        const GemmArgs pk = u_qkv_args(ctx, u.c.ctx_dim, kv2, tokens, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lkp);
+        e = gemm_launch(pk, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet kv)");
+    }
+    U_RC(u_attention(u, heads, hw, Lp, tokens, Lkp, u.ctxK, u.ctxVt, C, s));
+    U_RC(u_gemm(u.att, C, o2, o2.b, u.h, C, hw, EPI_RESID_F32, s));
+    // GEGLU feed-forward
+    U_RC(u_layernorm(u.h, u.xn, hw, C, w3, b3, 1e-5f, s));
+    U_RC(u_gemm(u.xn, C, f0, f0.b, u.ff, 8 * (int64_t)C, hw, EPI_BF16, s));
+    U_TRY(geglu_launch(u.ff, 8 * (int64_t)C, u.ff2, 4 * (int64_t)C, hw, 4 * C, s));
+    U_RC(u_gemm(u.ff2, 4 * (int64_t)C, f2, f2.b, u.h, C, hw, EPI_RESID_F32, s));
+    // proj_out + the block's input
+    U_TRY(f32_to_bf16_launch(u.h, u.xn, (int64_t)hw * C, s));
+    return u_gemm(u.xn, C, pout, pout.b, x, C, hw, EPI_RESID_F32, s);
+}
+
+// diffusers Downsample2D (conv 3x3, stride 2, padding 1)
+static int unet_downsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s) {
+    U_RC(u_check_shape(u, H, W, C, "r3g_unet_downsample"));
+    ULin cv;
+    U_RC(u_lin(u, pre + ".conv", true, C, 9 * C, &cv));
+    U_TRY(f32_to_bf16_launch(x, u.xn, (int64_t)H * W * C, s));
+    return u_conv3x3(u, u.xn, H, W, C, 2, cv, cv.b, out, EPI_F32, s);
+}
+
+static void unet_free(Unet* u) {
+    if (!u) return;
+    if (u->arena) (void)hipFree(u->arena);
+    delete u;
+}
+
+static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
+    if (ctx->unet) { unet_free((Unet*)ctx->unet); ctx->unet = nullptr; }
+    const r3g_unet_config& c = *cfg;
+    if (c.max_hw < 1 || c.max_channels < 64 || c.max_channels % 64 || c.max_channels > 2048 || c.temb_dim < 1 || c.temb_dim % 8 ||
+        c.ctx_dim % 64 || c.ctx_tokens < 1 || c.groups < 1 || c.groups > 256)
+        return fail(R3G_ERR_INVALID, "r3g_unet_create: bad configuration");
+    Unet* u = new Unet();
+    u->c = c;
+    const int64_t hw = c.max_hw, hwp = rup(hw, 128), C = c.max_channels, heads = C / 64, ckp = rup(c.ctx_tokens, 64);
+    size_t off = 0;
+    auto carve = [&](int64_t bytes) { size_t o = off; off += (size_t)rup(bytes, 256); return o; };
+    const size_t o_h = carve(hw * C * 4), o_t1 = carve(hw * C * 4), o_xn = carve(hw * C * 2), o_col = carve(hw * 9 * C * 2),
+                 o_q = carve(heads * hwp * 64 * 2), o_k = carve(heads * hwp * 64 * 2), o_v = carve(heads * hwp * 64 * 2),
+                 o_att = carve(hw * C * 2), o_ff = carve(hw * 8 * C * 2), o_ff2 = carve(hw * 4 * C * 2),
+                 o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
+                 o_gn = carve(256LL * 256 * 2 * 8);
+    hipError_t e = hipMalloc((void**)&u->arena, off);
+    if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMalloc(unet arena)"); }
+    e = hipMemset(u->arena, 0, off);      // padded rows must start finite
+    if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMemset(unet arena)"); }
+    char* a = u->arena;
+    u->h = (float*)(a + o_h); u->t1 = (float*)(a + o_t1); u->xn = (uint16_t*)(a + o_xn); u->col = (uint16_t*)(a + o_col);
+    u->Q = (uint16_t*)(a + o_q); u->K = (uint16_t*)(a + o_k); u->Vt = (uint16_t*)(a + o_v); u->att = (uint16_t*)(a + o_att);
+    u->ff = (uint16_t*)(a + o_ff); u->ff2 = (uint16_t*)(a + o_ff2); u->ctxK = (uint16_t*)(a + o_ck); u->ctxVt = (uint16_t*)(a + o_cv);
+    u->vec = (float*)(a + o_vec); u->gn_partial = (double*)(a + o_gn);
+    ctx->unet = u;
+    return R3G_OK;
+}
+
+}  // namespace r3g
+
+using namespace r3g;
+
+void r3g::Ctx::release_unet() {
+    if (unet) unet_free((Unet*)unet);
+    unet = nullptr;
+}
+
+#define NEED_UNET(fn)                                                                              \
+    Unet* u = ctx ? (Unet*)reinterpret_cast<Ctx*>(ctx)->unet : nullptr;                            \
+    if (!u) return fail(R3G_ERR_STATE, fn ": r3g_unet_create has not been called");
+
+extern "C" {
+
+int r3g_unet_create(r3g_ctx* ctx, const r3g_unet_config* cfg) {
+    if (!ctx || !cfg) return fail(R3G_ERR_INVALID, "r3g_unet_create: null argument");
+    return unet_create(reinterpret_cast<Ctx*>(ctx), cfg);
+}
+
+int r3g_unet_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols) {
+    NEED_UNET("r3g_unet_set_tensor");
+    if (!name || !d_ptr || (dtype != 0 && dtype != 1) || rows <= 0 || cols <= 0)
+        return fail(R3G_ERR_INVALID, "r3g_unet_set_tensor: bad argument for '%s'", name ? name : "?");
+    if (dtype == 1 && cols % 64) return fail(R3G_ERR_INVALID, "r3g_unet_set_tensor: '%s' K=%lld is not a multiple of 64", name, (long long)cols);
+    u->w[name] = UTensor{d_ptr, dtype, rows, cols};
+    return R3G_OK;
+}
+
+int r3g_unet_resnet(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int c_in, int c_out,
+                    const float* d_temb, float* d_out, void* stream) {
+    NEED_UNET("r3g_unet_resnet");
+    if (!prefix || !d_x || !d_temb || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_resnet: null argument");
+    return unet_resnet(*u, prefix, d_x, height, width, c_in, c_out, d_temb, d_out, (hipStream_t)stream);
+}
+
+int r3g_unet_transformer(r3g_ctx* ctx, const char* prefix, float* d_x, int height, int width, int channels, const uint16_t* d_ctx,
+                         int tokens, void* stream) {
+    NEED_UNET("r3g_unet_transformer");
+    if (!prefix || !d_x || !d_ctx) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: null argument");
+    return unet_transformer(*u, prefix, d_x, height, width, channels, d_ctx, tokens, (hipStream_t)stream);
+}
+
+int r3g_unet_downsample(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels, float* d_out,
+                        void* stream) {
+    NEED_UNET("r3g_unet_downsample");
+    if (!prefix || !d_x || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_downsample: null argument");
+    return unet_downsample(*u, prefix, d_x, height, width, channels, d_out, (hipStream_t)stream);
+}
+
+int r3g_unet_down_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int c_in, int c_out,
+                        const float* d_temb, const uint16_t* d_ctx, int tokens, int layers, int add_downsample, float* d_states,
+                        float* d_out, void* stream) {
+    NEED_UNET("r3g_unet_down_block");
+    if (!prefix || !d_x || !d_temb || !d_ctx || !d_states || layers < 1 || (add_downsample && !d_out))
+        return fail(R3G_ERR_INVALID, "r3g_unet_down_block: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const std::string pre = prefix;
+    const int64_t n = (int64_t)height * width * c_out;
+    // diffusers CrossAttnDownBlock2D.forward: every layer's hidden state is also an output (the skip connections of the up path)
+    const float* in = d_x;
+    int cin = c_in;
+    for (int i = 0; i < layers; ++i) {
+        float* dst = d_states + i * n;
+        int rc = unet_resnet(*u, pre + ".resnets." + std::to_string(i), in, height, width, cin, c_out, d_temb, dst, s);
+        if (rc) return rc;
+        rc = unet_transformer(*u, pre + ".attentions." + std::to_string(i), dst, height, width, c_out, d_ctx, tokens, s);
+        if (rc) return rc;
+        in = dst;
+        cin = c_out;
+    }
+    if (add_downsample) return unet_downsample(*u, pre + ".downsamplers.0", in, height, width, c_out, d_out, s);
+    return R3G_OK;
+}
+
+int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,
+                       const float* d_temb, const uint16_t* d_ctx, int tokens, float* d_out, void* stream) {
+    NEED_UNET("r3g_unet_mid_block");
+    if (!prefix || !d_x || !d_temb || !d_ctx || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_mid_block: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const std::string pre = prefix;
+    int rc = unet_resnet(*u, pre + ".resnets.0", d_x, height, width, channels, channels, d_temb, d_out, s);
+    if (rc) return rc;
+    rc = unet_transformer(*u, pre + ".attentions.0", d_out, height, width, channels, d_ctx, tokens, s);
+    if (rc) return rc;
+    return unet_resnet(*u, pre + ".resnets.1", d_out, height, width, channels, channels, d_temb, d_out, s);
+}
+
+}  // extern "C"

@@ -57,6 +57,13 @@ SYMBOLS = {
     "r3g_flow_sample_batch": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
     "r3g_vae_decode": (_I, [_P, _P, _P, _P]),
     "r3g_grid_query": (_I, [_P, _D, _I, _P, ctypes.c_int64, ctypes.c_int64, _P]),
+    "r3g_unet_create": (_I, [_P, _P]),
+    "r3g_unet_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
+    "r3g_unet_resnet": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "r3g_unet_transformer": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _I, _P]),
+    "r3g_unet_downsample": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _P]),
+    "r3g_unet_down_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "r3g_unet_mid_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
     "r3g_op_quant_fp8": (_I, [_P, ctypes.c_int64, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "r3g_op_gemm_fp8": (_I, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _P]),
@@ -79,6 +86,12 @@ class ModelConfig(ctypes.Structure):
         ("vae_scale_factor", ctypes.c_float)] + [(n, ctypes.c_int32) for n in (
             "cond_image_size", "cond_patch", "cond_hidden", "cond_layers", "cond_heads", "cond_ffn_hidden")] + [
         ("cond_ln_eps", ctypes.c_float), ("grid_chunk", ctypes.c_int32)]
+
+class UnetConfig(ctypes.Structure):
+    """struct r3g_unet_config (include/r3g.h)"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("max_hw", "max_channels", "temb_dim", "ctx_dim", "ctx_tokens", "groups")] + [
+        ("resnet_eps", ctypes.c_float)]
+
 
 _LIB = None
 _CTX = {}

@@ -1,0 +1,132 @@
+"""Host side of the texture stage's UNet blocks (include/r3g.h "UNet blocks"): diffusers state dict -> device weights in the
+layouts the kernels read, and thin methods over the C ABI.  SURVEY.md 8(f) rank 3, first slice: building blocks only --
+nothing in the stage uses them yet (hy3dgen.texgen keeps reporting where its colours come from).
+
+State-dict names are diffusers' (`unet/diffusion_pytorch_model.safetensors` of an SD-2.1-class model):
+"down_blocks.0.resnets.0.conv1.weight", "mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight", ...
+Activations cross this boundary as NCHW float tensors (diffusers' convention) and are turned into rows [H*W][C] here.
+"""
+import ctypes
+
+import torch
+
+from . import ffi as _l
+
+
+def prepare_weights(sd, device):
+    """pure re-layouts: 3x3 conv [O][I][3][3] -> [O][ky][kx][I]; 1x1 conv -> [O][I]; attn1 to_q|to_k|to_v -> to_qkv rows;
+    attn2 to_k / to_v -> per head (64 k rows, 64 v rows); matrices bf16, vectors f32"""
+    out = {}
+    groups = {}
+    for k, t in sd.items():
+        t = t.detach().to(torch.float32)
+        base, leaf = k.rsplit(".", 1)
+        parent, name = base.rsplit(".", 1) if "." in base else ("", base)
+        if name in ("to_q", "to_k", "to_v") and leaf == "weight":
+            groups.setdefault(parent, {})[name] = t
+            if name == "to_q" and parent.endswith("attn2"):
+                out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
+            continue
+        if t.ndim == 4:
+            t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1) if t.shape[-1] == 3 else t.reshape(t.shape[0], t.shape[1])
+        if t.ndim == 2:
+            out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
+        else:
+            out[k] = (t.reshape(1, -1).to(device=device).contiguous(), 0)
+    for parent, g in groups.items():
+        if parent.endswith("attn1"):
+            w = torch.cat([g["to_q"], g["to_k"], g["to_v"]], dim=0)
+            out[parent + ".to_qkv.weight"] = (w.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
+        else:
+            k_, v_ = g["to_k"], g["to_v"]
+            heads = k_.shape[0] // 64
+            w = torch.stack([k_.view(heads, 64, -1), v_.view(heads, 64, -1)], dim=1).reshape(2 * k_.shape[0], -1)
+            out[parent + ".to_kv.weight"] = (w.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
+    return out
+
+
+def to_rows(x):
+    """NCHW [1, C, H, W] -> rows f32 [H*W, C]"""
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).to(torch.float32).contiguous()
+
+
+def from_rows(r, h, w):
+    return r.reshape(h, w, -1).permute(2, 0, 1)[None].contiguous()
+
+
+class UnetBlocks:
+    def __init__(self, state_dict, max_hw, max_channels, temb_dim, ctx_dim, ctx_tokens, groups=32, resnet_eps=1e-5, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("r3g.unet needs an MI355X: libr3g has no CPU path")
+        self.device = torch.device("cuda", device)
+        self.ctx = _l.new_context(device)          # a context of its own: the shape model keeps the shared one
+        self.L = _l.lib()
+        c = _l.UnetConfig(int(max_hw), int(max_channels), int(temb_dim), int(ctx_dim), int(ctx_tokens), int(groups),
+                          float(resnet_eps))
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_create(self.ctx, ctypes.byref(c)))
+            self._w = prepare_weights(state_dict, self.device)
+            for name, (t, code) in self._w.items():
+                _l.check(self.L.r3g_unet_set_tensor(self.ctx, name.encode(), t.data_ptr(), code, t.shape[0], t.shape[1]))
+            torch.cuda.synchronize()
+
+    def _s(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _in(self, x, temb=None, ctx=None):
+        rows = to_rows(x.to(self.device))
+        t = None if temb is None else temb.reshape(-1).to(self.device, torch.float32).contiguous()
+        c = None if ctx is None else ctx[0].to(self.device, torch.bfloat16).contiguous()
+        return rows, t, c
+
+    def resnet(self, prefix, x, temb, c_out):
+        _, cin, h, w = x.shape
+        rows, t, _ = self._in(x, temb)
+        out = torch.empty((h * w, c_out), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_resnet(self.ctx, prefix.encode(), rows.data_ptr(), h, w, cin, c_out, t.data_ptr(),
+                                            out.data_ptr(), self._s()))
+        return from_rows(out, h, w)
+
+    def transformer(self, prefix, x, ctx):
+        _, c, h, w = x.shape
+        rows, _, cx = self._in(x, None, ctx)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_transformer(self.ctx, prefix.encode(), rows.data_ptr(), h, w, c, cx.data_ptr(),
+                                                 cx.shape[0], self._s()))
+        return from_rows(rows, h, w)
+
+    def downsample(self, prefix, x):
+        _, c, h, w = x.shape
+        rows, _, _ = self._in(x)
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        out = torch.empty((ho * wo, c), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_downsample(self.ctx, prefix.encode(), rows.data_ptr(), h, w, c, out.data_ptr(), self._s()))
+        return from_rows(out, ho, wo)
+
+    def down_block(self, prefix, x, temb, ctx, c_out, layers=2, add_downsample=True):
+        """-> (output, [hidden state of every layer (+ the downsampled output)]) as diffusers' CrossAttnDownBlock2D"""
+        _, cin, h, w = x.shape
+        rows, t, cx = self._in(x, temb, ctx)
+        states = torch.empty((layers, h * w, c_out), dtype=torch.float32, device=self.device)
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        out = torch.empty((ho * wo, c_out), dtype=torch.float32, device=self.device) if add_downsample else None
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_down_block(self.ctx, prefix.encode(), rows.data_ptr(), h, w, cin, c_out, t.data_ptr(),
+                                                cx.data_ptr(), cx.shape[0], layers, int(bool(add_downsample)),
+                                                states.data_ptr(), out.data_ptr() if add_downsample else None, self._s()))
+        st = [from_rows(states[i], h, w) for i in range(layers)]
+        if add_downsample:
+            o = from_rows(out, ho, wo)
+            return o, st + [o]
+        return st[-1], st
+
+    def mid_block(self, prefix, x, temb, ctx):
+        _, c, h, w = x.shape
+        rows, t, cx = self._in(x, temb, ctx)
+        out = torch.empty((h * w, c), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_mid_block(self.ctx, prefix.encode(), rows.data_ptr(), h, w, c, t.data_ptr(), cx.data_ptr(),
+                                               cx.shape[0], out.data_ptr(), self._s()))
+        return from_rows(out, h, w)

@@ -8,7 +8,7 @@
 A "step" is ONE object: a synthetic 512x512 RGBA crop (host PIL image, as the segmentation stage hands it over)
 -> preprocess -> DINOv2-g conditioner -> 50-step flow-matching DiT with CFG (batch 2) -> shape-VAE decode ->
 dense 257^3 occupancy-grid query -> Lewiner marching cubes, mesh left in HBM.  The crops of a scene are independent:
---objects-per-launch of them (default 2) share the launches of the denoising loop (upstream's batch dimension; each
+--objects-per-launch of them (default 4) share the launches of the denoising loop (upstream's batch dimension; each
 object's result is bit-identical to its single-object run, tests/test_model_gpu.py), everything else runs per object.  Model load, mesh cleaners,
 texture generation and GLB export are outside the metric.  Workload at N=1 = BASELINE.json
 configs[1] ("1 scene / 8 object crops, Hunyuan3D-2 base bf16, 50 steps, 256^3 grid"): the default --steps 8 is
@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--model", default="full", choices=["full", "mini"])
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--octree-resolution", type=int, default=256)
-    ap.add_argument("--objects-per-launch", type=int, default=2,
+    ap.add_argument("--objects-per-launch", type=int, default=4,
                     help="crops that share the launches of the denoising loop (1 = one object at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

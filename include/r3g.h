@@ -224,6 +224,49 @@ int r3g_vae_decode(r3g_ctx* ctx, const float* d_latents, float* d_z_out, void* s
 int r3g_grid_query(r3g_ctx* ctx, double bound, int octree_resolution, float* d_grid, int64_t start, int64_t count,
                    void* stream);
 
+/* ---- texture stage: UNet blocks (first slice) -------------------------------------------
+ * The two diffusion models behind upstream's Hunyuan3DPaintPipeline.__call__ (reference call site
+ * src/2d_to_3d_models/run.py:97; built at :126-128, :207-209) are diffusers UNet2DConditionModels on the Stable-Diffusion-2.1
+ * layout.  These entry points are their building blocks on gfx950 -- ResnetBlock2D, Transformer2DModel
+ * (use_linear_projection, one BasicTransformerBlock: self-attention, cross-attention over the context, GEGLU feed-forward),
+ * Downsample2D, and the compositions CrossAttnDownBlock2D / UNetMidBlock2DCrossAttn; conv_in / conv_out, the up blocks, the
+ * VAE and the schedulers are NOT part of this library yet (the stage keeps reporting where its colours come from).
+ * Activations are rows: f32 [height*width][channels] (NHWC: a pixel's channels contiguous; channels % 64 == 0, head dim
+ * 64), the context bf16 [tokens][ctx_dim], the time embedding f32 [temb_dim] (the output of the UNet's time_embedding MLP).
+ * Weights are registered under diffusers' state-dict names below `prefix` ("down_blocks.0", "mid_block", ...):
+ *   3x3 convolutions bf16 [C_out][9 C_in] with column (ky*3 + kx)*C_in + c (a re-layout of torch's [C_out][C_in][3][3]),
+ *   linear layers bf16 [N][K], vectors f32; fused projections registered as "<block>.attn1.to_qkv.weight" = rows of to_q, to_k,
+ *   to_v and "<block>.attn2.to_kv.weight" = per head its 64 rows of to_k then its 64 rows of to_v (pure re-layouts, done by
+ *   r3g/unet.py).  All calls enqueue on `stream` and return. */
+typedef struct r3g_unet_config {
+    int32_t max_hw;         /* largest height*width an entry point will see */
+    int32_t max_channels;   /* largest channel count (multiple of 64, <= 2048) */
+    int32_t temb_dim;       /* 1280 for SD 2.1 */
+    int32_t ctx_dim;        /* cross_attention_dim: 1024 for SD 2.1 */
+    int32_t ctx_tokens;     /* most context tokens (77 for CLIP text) */
+    int32_t groups;         /* norm_num_groups: 32 */
+    float resnet_eps;       /* GroupNorm eps of the resnets: 1e-5 (Transformer2DModel's norm uses 1e-6, its LayerNorms 1e-5) */
+} r3g_unet_config;
+int r3g_unet_create(r3g_ctx* ctx, const r3g_unet_config* cfg);
+int r3g_unet_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols);
+/* ResnetBlock2D.forward(x, temb) -> d_out f32 [height*width][c_out] (may alias d_x when c_in == c_out) */
+int r3g_unet_resnet(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int c_in, int c_out,
+                    const float* d_temb, float* d_out, void* stream);
+/* Transformer2DModel.forward(x, encoder_hidden_states), in place on d_x */
+int r3g_unet_transformer(r3g_ctx* ctx, const char* prefix, float* d_x, int height, int width, int channels, const uint16_t* d_ctx,
+                         int tokens, void* stream);
+/* Downsample2D.forward: conv 3x3, stride 2, padding 1 -> d_out f32 [(height+1)/2 * (width+1)/2][channels] */
+int r3g_unet_downsample(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels, float* d_out,
+                        void* stream);
+/* CrossAttnDownBlock2D.forward: `layers` x (resnet, transformer) [+ downsample].  d_states f32 [layers][height*width][c_out]
+ * receives every layer's hidden state (diffusers' output_states: the skip connections); d_out the downsampled result. */
+int r3g_unet_down_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int c_in, int c_out,
+                        const float* d_temb, const uint16_t* d_ctx, int tokens, int layers, int add_downsample, float* d_states,
+                        float* d_out, void* stream);
+/* UNetMidBlock2DCrossAttn.forward: resnet, transformer, resnet -> d_out f32 [height*width][channels] */
+int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,
+                       const float* d_temb, const uint16_t* d_ctx, int tokens, float* d_out, void* stream);
+
 /* ---- single kernels, for parity tests through the ABI ------------------------------------------ */
 /* C = epilogue(A[m][k] . W[n][k]^T + bias); epilogue: 0 bf16, 1 bf16 gelu(tanh), 2 bf16 gelu(erf),
  * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
@@ -254,7 +297,9 @@ int r3g_prof_read_bytes(double* bytes, int n);
 /* A/B switches for tests and ablations.  Default 1: "fuse_qkv" (QKV split/norm/transpose in the projection epilogue
  * vs a separate kernel), "batch_mods" (all adaLN modulations of a forward in one GEMV launch), "lds_dma"
  * (= r3g_set_staging), "cfg_dedup" (one weighted token for a uniform unconditional context), "group_streams" (img and
- * txt stream of a double block in one GEMM / LayerNorm launch), "skip_zero_step" (the DiT evaluation of a step with d_sigma = 0 --
+ * txt stream of a double block in one GEMM / LayerNorm launch), "geo_q_cache" (1: the part of the geo decoder that does not depend on the object -- Fourier features, query_proj, ln_1, c_q,
+ * q-norm of every grid point -- stays resident in HBM after its first evaluation, 2 x 34.8 GB at 257^3, and is read instead of
+ * recomputed; bit-identical; skipped by itself when the memory is not there), "skip_zero_step" (the DiT evaluation of a step with d_sigma = 0 --
  * upstream's last step -- is skipped: x += 0 * v), "overlap_mlp" (0 default | 1: MLP half of a single block's linear1
  * on a second stream beside the attention kernel), "gemm_wide_epilogue" (stores through the LDS transpose).
  * Tuning: "gemm_waves" (0 auto | 4 | 8 | 9 = 256x256 two-stage | 10 = 256x128 | 11 = 256x256 phased | 12 = phased,
@@ -263,7 +308,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * with more tiles than CUs), "gemm_num_cu" (CUs the tile rules assume, default 256), "gemm_auto_rule" (2: the current
  * tile-choice rule | 1: round 2's | 0: round 1's first version), "attn_generation" (7 default: 6 where its
  * 256-query workgroups make four rounds of the device, otherwise 2 | 2 = four waves of 32 queries | 6 = four waves of 64
- * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
+ * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_wide_min" (2048: work items of 256 queries from which attn_generation 7 takes generation 6), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
  * LayerNorm / ln_dot row kernels), "ln_fixed" (1: their instantiations with a compile-time row length for C = 1024 / 1536), "attn_pipelined" (0), "attn_ablate"
  * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:

@@ -332,6 +332,50 @@ def test_vae_and_grid_query(tiny):
     assert torch.isnan(pf[:1000]).all() and torch.isnan(pf[1777:]).all()
 
 
+def test_query_side_cache_of_the_geo_decoder_is_bit_identical(tiny):
+    """option geo_q_cache: what a grid point computes before it meets the object's latents (Fourier features, query_proj, ln_1,
+    c_q, q-norm) stays in HBM after its first evaluation.  First pass (builds), second pass (hits), another object (hits),
+    cache off, a sub-range query in the middle of a pass, and new weights (the cache must be dropped) -- all bit-identical."""
+    import torch
+    from r3g import ffi
+    from r3g import model as M
+    L = ffi.lib()
+    g = torch.Generator().manual_seed(18)
+    lat_a = torch.randn(tiny.cfg["vae"]["num_latents"], tiny.cfg["vae"]["embed_dim"], generator=g)
+    lat_b = torch.randn(tiny.cfg["vae"]["num_latents"], tiny.cfg["vae"]["embed_dim"], generator=g)
+    R = 40                                   # 41^3 = 68 921 points = 16 full passes of 4 096 + a partial one
+    m = M.ShapeModel(tiny.cfg, tiny.sd, 0, grid_chunk=4096)
+    try:
+        ffi.check(L.r3g_set_option(b"geo_q_cache", 0))
+        m.vae_decode(lat_a)
+        ref_a = m.grid_query(1.01, R).clone()
+        m.vae_decode(lat_b)
+        ref_b = m.grid_query(1.01, R).clone()
+        ffi.check(L.r3g_set_option(b"geo_q_cache", 1))
+        m.vae_decode(lat_a)
+        assert torch.equal(m.grid_query(1.01, R), ref_a)          # builds the cache
+        assert torch.equal(m.grid_query(1.01, R), ref_a)          # served from it
+        m.vae_decode(lat_b)
+        assert torch.equal(m.grid_query(1.01, R), ref_b)          # another object, same cache
+        part = torch.zeros_like(ref_b)
+        m.grid_query(1.01, R, out=part, start=5000, count=9000)   # starts inside a pass: computed the old way
+        assert torch.equal(part.reshape(-1)[5000:14000], ref_b.reshape(-1)[5000:14000])
+        part.zero_()
+        m.grid_query(1.01, R, out=part, start=8192, count=4096 * 3 + 5)   # canonical passes 2..4 from the cache + a fragment
+        assert torch.equal(part.reshape(-1)[8192:8192 + 4096 * 3 + 5], ref_b.reshape(-1)[8192:8192 + 4096 * 3 + 5])
+        # other weights through the same context: the cache of the old ones must not survive
+        from oracle import hy3d_torch as H
+        sd2 = bf16_round_matrices(H.synthetic_state_dict(tiny.cfg, seed=77))
+        m2 = M.ShapeModel(tiny.cfg, sd2, 0, grid_chunk=4096)
+        m2.vae_decode(lat_a)
+        with_cache = m2.grid_query(1.01, R).clone()
+        ffi.check(L.r3g_set_option(b"geo_q_cache", 0))
+        m2.vae_decode(lat_a)
+        assert torch.equal(m2.grid_query(1.01, R), with_cache) and not torch.equal(with_cache, ref_a)
+    finally:
+        ffi.check(L.r3g_set_option(b"geo_q_cache", 1))
+
+
 def test_grid_is_independent_of_internal_chunking(tiny):
     import torch
     from r3g import model as M

@@ -292,9 +292,11 @@ def test_objects_per_launch_groups_give_the_same_files(tmp_path):
     cfg, inp, out, names = make_distinct_scene(tmp_path, 5)
     assert stage.main(["--config", cfg], factory=content_factory) == 0
     ref = _glbs(out)
-    for per, want in ((1, [1, 1, 1, 1, 1]), (2, [2, 2, 1]), (4, [4, 1])):
+    for per, want in ((1, [1, 1, 1, 1, 1]), (2, [2, 2, 1]), (4, [4, 1]), (None, [4, 1])):
         conf = yaml.safe_load(open(cfg))
-        conf["r3g_objects_per_launch"] = per
+        conf.pop("r3g_objects_per_launch", None)
+        if per is not None:
+            conf["r3g_objects_per_launch"] = per
         open(cfg, "w").write(yaml.safe_dump(conf))
         seen = {}
 
