@@ -252,9 +252,19 @@ __global__ __launch_bounds__(256) void fill_u32(unsigned* p, int64_t n, unsigned
     if (i < n) p[i] = v;
 }
 
+// The texel a face corner takes its vertex colour from: the corner's UV pulled a quarter of the way towards the centroid of
+// its chart triangle.  (The texel nearest to the corner itself usually lies OUTSIDE the triangle -- with one chart per face
+// its centre is beyond the chart's edge, unpainted -- so most corners gave no seed and the vertex colours came from a few
+// texels spread by propagation.)  fp32, products rounded before the sums (-ffp-contract=off): oracle/tex_ref.py repeats it.
 __device__ __forceinline__ int64_t corner_texel(const float* uv, const int32_t* uv_tri, int64_t corner, int T) {
-    const int64_t j = uv_tri[corner];
-    return (int64_t)texel_of(uv[2 * j + 1], T) * T + texel_of(uv[2 * j], T);
+    const int64_t f3 = corner - corner % 3;
+    const int64_t j = uv_tri[corner], j0 = uv_tri[f3], j1 = uv_tri[f3 + 1], j2 = uv_tri[f3 + 2];
+    const float third = 1.0f / 3.0f;
+    const float cu = ((uv[2 * j0] + uv[2 * j1]) + uv[2 * j2]) * third;
+    const float cv = ((uv[2 * j0 + 1] + uv[2 * j1 + 1]) + uv[2 * j2 + 1]) * third;
+    const float pu = uv[2 * j] * 0.75f + cu * 0.25f;
+    const float pv = uv[2 * j + 1] * 0.75f + cv * 0.25f;
+    return (int64_t)texel_of(pv, T) * T + texel_of(pu, T);
 }
 
 __global__ __launch_bounds__(256) void vertex_owner_kernel(const uint8_t* __restrict__ mask, int T, const float* __restrict__ uv,
@@ -450,15 +460,25 @@ hipError_t tex_inpaint(char* ws, unsigned* h_flag, float* tex, uint8_t* mask, in
     hipLaunchKernelGGL(vertex_owner_kernel, blocks(nc), dim3(256), 0, s, mask, T, uv, uv_tri, pos_tri, nc, owner);
     hipLaunchKernelGGL(vertex_gather_kernel, blocks(V), dim3(256), 0, s, tex, T, uv, uv_tri, owner, V, vcolor, vm[0]);
     if ((e = hipMemsetAsync(acc, 0, 32 * (size_t)V, s)) != hipSuccess) return e;
+    // Jacobi rounds until nothing changes.  A round after convergence is a no-op, so the convergence flag is read back
+    // once per batch of kBatch rounds (one host synchronisation per batch instead of per round); every round of a batch
+    // has a flag of its own, so the number of rounds that changed something is still exact.
+    constexpr int kBatch = 8;
     int cur = 0, rounds = 0;
-    for (; rounds < 8192; ++rounds) {
-        if ((e = hipMemsetAsync(flag, 0, 4, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(propagate_edges_kernel, blocks(nc), dim3(256), 0, s, verts, pos_tri, nc, vcolor, vm[cur], acc);
-        hipLaunchKernelGGL(propagate_commit_kernel, blocks(V), dim3(256), 0, s, V, acc, vcolor, vm[cur], vm[cur ^ 1], flag);
-        cur ^= 1;
-        if ((e = hipMemcpyAsync(h_flag, flag, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    bool done = false;
+    while (!done && rounds < 8192) {
+        if ((e = hipMemsetAsync(flag, 0, 4 * kBatch, s)) != hipSuccess) return e;
+        for (int k = 0; k < kBatch; ++k) {
+            hipLaunchKernelGGL(propagate_edges_kernel, blocks(nc), dim3(256), 0, s, verts, pos_tri, nc, vcolor, vm[cur], acc);
+            hipLaunchKernelGGL(propagate_commit_kernel, blocks(V), dim3(256), 0, s, V, acc, vcolor, vm[cur], vm[cur ^ 1], flag + k);
+            cur ^= 1;
+        }
+        if ((e = hipMemcpyAsync(h_flag, flag, 4 * kBatch, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        if (*h_flag == 0u) break;
+        for (int k = 0; k < kBatch; ++k) {
+            if (h_flag[k] == 0u) { done = true; break; }
+            ++rounds;
+        }
     }
     if (rounds_out) *rounds_out = rounds;
     hipLaunchKernelGGL(fill_texels_kernel, blocks(nt), dim3(256), 0, s, findices_uv, bary_uv, pos_tri, vcolor, vm[cur], nt, tex, mask);

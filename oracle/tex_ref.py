@@ -206,7 +206,15 @@ def inpaint(tex, mask, findices_uv, bary_uv, verts, pos_tri, uv, uv_tri, dilate_
     pos_c = np.asarray(pos_tri, np.int64).reshape(-1)
     uv_c = np.asarray(uv_tri, np.int64).reshape(-1)
     V = len(verts)
-    corner_tex = _texel(uv[uv_c, 1], T) * T + _texel(uv[uv_c, 0], T)
+    # the texel a corner takes its vertex colour from: the corner's UV pulled a quarter of the way to the chart triangle's centroid
+    f3 = (np.arange(len(uv_c)) // 3) * 3
+    j0, j1, j2 = uv_c[f3], uv_c[f3 + 1], uv_c[f3 + 2]
+    third = F32(1.0) / F32(3.0)
+    cu = ((uv[j0, 0] + uv[j1, 0]) + uv[j2, 0]) * third
+    cv = ((uv[j0, 1] + uv[j1, 1]) + uv[j2, 1]) * third
+    pu = uv[uv_c, 0] * F32(0.75) + cu * F32(0.25)
+    pv = uv[uv_c, 1] * F32(0.75) + cv * F32(0.25)
+    corner_tex = _texel(pv.astype(F32), T) * T + _texel(pu.astype(F32), T)
     owner = np.full(V, 0xFFFFFFFF, np.uint64)
     painted = mask[corner_tex] > 0
     np.minimum.at(owner, pos_c[painted], np.nonzero(painted)[0].astype(np.uint64))

@@ -79,3 +79,26 @@ def test_bake_recovers_a_constant_and_inpaint_completes_a_sphere():
     assert ((mask2 > 0) | (fi_uv == 0)).all() or (mask2[fi_uv > 0] > 0).all()    # every covered texel has a colour
     assert np.allclose(tex2[mask2 > 0], (0.25, 0.5, 0.75), atol=1e-4)              # a constant stays a constant
     assert (mask2 == 3).sum() > 0 and ((mask2 > 0).sum() > (fi_uv > 0).sum())      # the dilation grew into the gutter
+
+
+def test_vertex_colours_are_seeded_inside_the_chart():
+    """the texel nearest to a chart CORNER usually lies outside the triangle (unpainted), so most corners gave no
+    seed.  With the seed pulled a quarter of the way to the chart's centroid, a texture that is painted on every covered
+    texel seeds every vertex directly: no propagation round is needed, and a vertex's colour is its own chart's colour."""
+    v, f = ts.icosphere(2)
+    T = 256
+    uv, uv_tri = ts.face_atlas(f, T)
+    uvc = np.concatenate([uv * 2 - 1, np.zeros((len(uv), 1), np.float32), np.ones((len(uv), 1), np.float32)], 1)
+    fi_uv, bary_uv = tex_ref.rasterize(uvc, uv_tri, T, T)
+    covered = fi_uv > 0
+    rng = np.random.default_rng(0)
+    face_colour = rng.uniform(0.1, 0.9, (len(f), 3)).astype(np.float32)
+    tex = np.zeros((T, T, 3), np.float32)
+    tex[covered] = face_colour[fi_uv[covered] - 1]
+    mask = covered.astype(np.uint8)
+    tex2, mask2, rounds = tex_ref.inpaint(tex, mask, fi_uv, bary_uv, v, f, uv, uv_tri, dilate_iters=0)
+    assert rounds == 0                                    # every vertex found a painted texel inside one of its charts
+    assert np.array_equal(tex2[covered], tex[covered])    # painted texels are never touched
+    # half of the corners' own nearest texels are NOT covered: that is what the old rule looked at
+    own = (np.clip((uv[:, 1] * (T - 1) + 0.5).astype(int), 0, T - 1), np.clip((uv[:, 0] * (T - 1) + 0.5).astype(int), 0, T - 1))
+    assert (~covered[own]).mean() > 0.3
