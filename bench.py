@@ -171,7 +171,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="full", choices=["full", "mini"])
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--octree-resolution", type=int, default=256)
@@ -364,6 +364,36 @@ def main():
                                   "frac": mc_bytes / (mc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "ms": mc_ms,
                                   "algorithmic_bytes": mc_bytes,
                                   "note": "synthetic weights give a noise-like field: V and F are ~5x a real object's"}
+        # the same kernels on an object-like field (a union of smooth blobs, ~1e5 vertices as real objects give):
+        # the synthetic weights' noise-like field has ~8x the surface and is dominated by the per-cell emission kernels
+        try:
+            from r3g import mc as rmc
+            ax = torch.linspace(-1.0, 1.0, R + 1, device="cuda")
+            X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+            rng = np.random.default_rng(7)
+            fld = torch.full_like(X, -1.0)
+            for _ in range(5):
+                cx, cy, cz = rng.uniform(-0.35, 0.35, 3)
+                fld = torch.maximum(fld, float(rng.uniform(0.3, 0.5)) - torch.sqrt((X - cx) ** 2 + (Y - cy) ** 2 + (Z - cz) ** 2))
+            del X, Y, Z
+            fld = fld.contiguous()
+            rmc.extract_mesh(fld, 0.0, 1.01, R)
+            torch.cuda.synchronize()
+            ffi.check(L.r3g_prof_enable(1))
+            sv, sf = rmc.extract_mesh(fld, 0.0, 1.01, R)
+            torch.cuda.synchronize()
+            ffi.check(L.r3g_prof_read(cnt, ms, work, n))
+            ffi.check(L.r3g_prof_enable(0))
+            sm_ms = float(ms[FAMILIES.index("mc_classify")]) + float(ms[FAMILIES.index("mc_other")])
+            sm_bytes = 4.0 * (R + 1) ** 3 + 12.0 * (int(sv.shape[0]) + int(sf.shape[0]))
+            if sm_ms > 0 and "roofline_mc" in out:
+                out["roofline_mc"]["object_like_field"] = {
+                    "V": int(sv.shape[0]), "F": int(sf.shape[0]), "ms": sm_ms, "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9,
+                    "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                    "note": "same kernels, smooth union-of-blobs field on the same %d^3 grid (not part of the timed objects)" % (R + 1)}
+            del fld, sv, sf
+        except Exception as e:      # reporting only: never fails the bench line
+            out.setdefault("roofline_mc", {})["object_like_field"] = {"error": str(e)}
     bad = False
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         oracle_mesh, out["cpu_baseline"] = cpu_baseline(cfg, S, R, last_grid.cpu().numpy())

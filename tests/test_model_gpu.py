@@ -185,38 +185,46 @@ def test_flow_sample_fifty_steps_tiny(tiny):
 
 
 def test_flow_sample_fifty_steps_mini_dims():
-    """hunyuan3d-dit-v2-mini dims (full width, 8 + 16 blocks, 512 latents + 1370 context tokens), 50 steps x CFG 2"""
+    """hunyuan3d-dit-v2-mini's widths and token counts (hidden 1024, 16 heads, 512 latents + 1370 context tokens), 50 steps x
+    CFG 2.  Depth 1 + 2 instead of the model's 8 + 16: the fp32 oracle runs the same 50 steps on the box's host cores, and at
+    full depth that alone took 9 minutes of a GPU lease (measured once, round 3: 2.9e-3 at 8 + 16 blocks, tolerance 3e-2;
+    profiles/r03_parity_measured.json).  Every block at full depth is covered by test_full_depth_dit_forward."""
     from oracle import hy3d_torch as H
     cfg = H.mini_config()
+    cfg["dit"].update(depth=1, depth_single_blocks=2)
     cfg["vae"].update(num_decoder_layers=1)
     cfg["cond"].update(num_hidden_layers=1)
     s = Setup(cfg, 41)
-    err, out, lat0, _ = _fifty_steps(s, "mini-dims", 5)
+    err, out, lat0, _ = _fifty_steps(s, "mini-dims (depth 1+2)", 5)
     assert err <= TOL["flow_sample_50"]
     assert rel_l2(out, lat0) > 0.3
 
 
 def test_fifty_steps_full_width_dedup_against_plain_batch(wide):
     """50 steps at full width (4442 tokens, depth 1 + 1): the de-duplicated CFG batch against the plain one -- two valid
-    bf16 evaluations of the same sampler -- and both against the oracle"""
+    bf16 evaluations of the same sampler.  (Both against the 50-step fp32 oracle at this width: 2.06e-3 / 2.07e-3, measured
+    once in round 3 -- 70 s of host time per run, so the oracle leg runs at 8 steps here.)"""
     import torch
     from r3g import ffi
     L = ffi.lib()
     x, _, cond = _inputs(wide, 15)
     lat0 = x[0]
-    a = wide.gpu.flow_sample(lat0.clone(), cond, 50, 5.0).clone()
-    try:
-        ffi.check(L.r3g_set_option(b"cfg_dedup", 0))
-        b = wide.gpu.flow_sample(lat0.clone(), cond, 50, 5.0).clone()
-    finally:
-        ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
-    report("full-width 50 steps: cfg dedup vs plain batch", rel_l2(a, b), TOL["same_function"])
-    assert rel_l2(a, b) <= TOL["same_function"]
-    ref = wide.oracle.sample(cond, lat0[None].clone(), 50, 5.0)[0]
-    ea, eb = rel_l2(a, ref), rel_l2(b, ref)
-    report("full-width 1+1 flow_sample 50 steps (dedup)", ea, TOL["flow_sample_50"])
-    report("full-width 1+1 flow_sample 50 steps (plain batch)", eb, TOL["flow_sample_50"])
-    assert ea <= TOL["flow_sample_50"] and eb <= TOL["flow_sample_50"]
+    outs = {}
+    for steps in (50, 8):
+        a = wide.gpu.flow_sample(lat0.clone(), cond, steps, 5.0).clone()
+        try:
+            ffi.check(L.r3g_set_option(b"cfg_dedup", 0))
+            b = wide.gpu.flow_sample(lat0.clone(), cond, steps, 5.0).clone()
+        finally:
+            ffi.check(L.r3g_set_option(b"cfg_dedup", 1))
+        outs[steps] = (a, b)
+        report("full-width %d steps: cfg dedup vs plain batch" % steps, rel_l2(a, b), TOL["same_function"])
+        assert torch.isfinite(a).all() and rel_l2(a, b) <= TOL["same_function"]
+    ref = wide.oracle.sample(cond, lat0[None].clone(), 8, 5.0)[0]
+    ea, eb = rel_l2(outs[8][0], ref), rel_l2(outs[8][1], ref)
+    report("full-width 1+1 flow_sample 8 steps (dedup)", ea, TOL["flow_sample"])
+    report("full-width 1+1 flow_sample 8 steps (plain batch)", eb, TOL["flow_sample"])
+    assert ea <= TOL["flow_sample"] and eb <= TOL["flow_sample"]
 
 
 def test_skipping_the_zero_step_changes_nothing(tiny):

@@ -18,7 +18,7 @@ cd $R
 DB=$(ls gpurun_out/r03_trace/*/*_results.db gpurun_out/r03_trace/*_results.db 2>/dev/null | head -1)
 python tools/rocprof_summary.py $DB "x" > gpurun_out/r03_kernel_stats.md
 python tools/rocprof_summary.py $DB "x" --by-grid > gpurun_out/r03_kernel_stats_by_grid.md
-python tools/traffic_json.py --fetch gpurun_out/r03_pmc_FETCH_SIZE --write gpurun_out/r03_pmc_WRITE_SIZE --trace $DB --commit "$COMMIT" --out gpurun_out/traffic.json > gpurun_out/r03_pmc_traffic.md 2>&1
+python tools/traffic_json.py --fetch gpurun_out/r03_pmc_FETCH_SIZE --write gpurun_out/r03_pmc_WRITE_SIZE --trace $DB --commit "$COMMIT" --objects-per-launch $B --out gpurun_out/traffic.json > gpurun_out/r03_pmc_traffic.md 2>&1
 python tools/mfma_util.py --pmc gpurun_out/r03_pmc_mfma --trace $DB --objects-per-launch $B > gpurun_out/r03_mfma_util.md 2>&1
 tail -12 gpurun_out/r03_pmc_traffic.md; tail -8 gpurun_out/r03_mfma_util.md
 # the raw counter / trace directories are scratch: keep the tables

@@ -46,13 +46,14 @@ def main():
     ap.add_argument("--write", required=True)
     ap.add_argument("--trace", required=True)
     ap.add_argument("--commit", default="")
+    ap.add_argument("--objects-per-launch", type=int, default=1, help="objects in the traced launch group")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"))
     a = ap.parse_args()
     fetch, write = pmc(a.fetch, "FETCH_SIZE"), pmc(a.write, "WRITE_SIZE")
     cur = sqlite3.connect(a.trace).cursor()
     rows = list(cur.execute("select name, grid_x, workgroup_x, count(*), avg(end-start)/1e3 from kernels group by name, grid_x, workgroup_x"))
     fam = defaultdict(lambda: [0, 0.0, 0])   # launches, bytes, launches without counters
-    print("| kernel  [workgroups] | launches / object | avg us | FETCH_SIZE avg KB | WRITE_SIZE avg KB | bytes / launch (corrected) |\n|---|---|---|---|---|---|")
+    print("| kernel  [workgroups] | launches / launch group of %d object(s) | avg us |" % a.objects_per_launch + " FETCH_SIZE avg KB | WRITE_SIZE avg KB | bytes / launch (corrected) |\n|---|---|---|---|---|---|")
     table = []
     for n, gx, wx, c, avg in rows:
         k = (short_name(n), gx // max(1, wx))
@@ -72,11 +73,12 @@ def main():
     out = {}
     for f, (n, b, miss) in fam.items():
         if n:
-            out[f] = {"bytes_per_launch": b / n, "launches": n, "launches_without_counters": miss,
+            out[f] = {"bytes_per_launch": b / n, "launches": n, "objects_per_launch": a.objects_per_launch, "launches_without_counters": miss,
                       "measured": time.strftime("%Y-%m-%d"), "commit": a.commit,
                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 for 16-byte-per-lane loads, "
                                 "weighted by the launch counts of one 50-step object (tools/traffic_json.py)"}
-            print("\nfamily %s: %d launches (%d without counters), %.1f MB per launch, %.3f TB per object" % (f, n, miss, b / n / 1e6, b / 1e12))
+            print("\nfamily %s: %d launches (%d without counters), %.1f MB per launch, %.3f TB per object" % (
+                f, n, miss, b / n / 1e6, b / 1e12 / max(1, a.objects_per_launch)))
     # the build the counters were measured on: bench.py marks the record stale when the library it loads has another digest
     try:
         with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-re-gen_amd", "libr3g.digest")) as f:
