@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void fill_u32(unsigned* p, int64_t n, unsigned
 // The texel a face corner takes its vertex colour from: the corner's UV pulled a quarter of the way towards the centroid of
 // its chart triangle.  (The texel nearest to the corner itself usually lies OUTSIDE the triangle -- with one chart per face
 // its centre is beyond the chart's edge, unpainted -- so most corners gave no seed and the vertex colours came from a few
-// texels spread by propagation.)  fp32, products rounded before the sums (-ffp-contract=off): oracle/tex_ref.py repeats it.
+// texels spread by propagation.)  fp32, products rounded before the sums (-ffp-contract=off): the numpy restatement used by the tests repeats it.
 __device__ __forceinline__ int64_t corner_texel(const float* uv, const int32_t* uv_tri, int64_t corner, int T) {
     const int64_t f3 = corner - corner % 3;
     const int64_t j = uv_tri[corner], j0 = uv_tri[f3], j1 = uv_tri[f3 + 1], j2 = uv_tri[f3 + 2];
