@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restri
 
 // ---- GroupNorm, pass 1: block b sums rows [b*rpb, (b+1)*rpb) per channel (thread t owns channels t, t + 256, ...), folds
 // the channels of a group in LDS and writes (sum, sum of squares) per group as fp64 to partial[b][g][2]
-constexpr int GN_MAX_CPT = 8;   // channels per thread: C <= 2048
+constexpr int GN_MAX_CPT = 12;   // channels per thread: C <= 3072 (the up blocks normalise cat(hidden, skip): 2560 channels)
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int C, int groups, int rpb,
                                                          double* __restrict__ partial) {
-    __shared__ float s_sum[2048], s_sq[2048];
+    __shared__ float s_sum[256 * GN_MAX_CPT], s_sq[256 * GN_MAX_CPT];
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
     float a[GN_MAX_CPT], q[GN_MAX_CPT];
@@ -151,6 +151,33 @@ __global__ __launch_bounds__(256) void geglu_kernel(const uint16_t* __restrict__
     *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + c) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// nearest-neighbour 2x upsampling of f32 rows [H][W][C] -> bf16 rows [2H][2W][C] (the operand of Upsample2D's convolution)
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, int H, int W, int C, uint16_t* __restrict__ y) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)4 * H * W * c4n;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c4n) * 4;
+    const int64_t m = i / c4n;
+    const int oy = (int)(m / (2 * W)), ox = (int)(m % (2 * W));
+    const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(oy >> 1) * W + (ox >> 1)) * C + c);
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(y + m * C + c) = pk;
+}
+
+// diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): out[dim] = [cos(t f_k) | sin(t f_k)],
+// f_k = exp(-ln(10000) k / (dim/2))
+__global__ void unet_timestep_kernel(float t, int dim, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim >> 1;
+    if (k >= half) return;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    out[k] = cosf(t * f);
+    out[half + k] = sinf(t * f);
+}
+
 __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
@@ -190,6 +217,20 @@ hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t 
     if (F % 8 || (ldi & 7) || (ldo & 7)) return hipErrorInvalidValue;
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(geglu_kernel, dim3(blocks_for((int64_t)rows * F / 8, 256)), dim3(256), 0, s, in, ldi, out, ldo, rows, F);
+    return hipGetLastError();
+}
+
+hipError_t upsample2x_launch(const float* x, int H, int W, int C, uint16_t* y, hipStream_t s) {
+    if (C % 4 || H < 1 || W < 1) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for((int64_t)4 * H * W * (C / 4), 256)), dim3(256), 0, s, x, H, W, C, y);
+    return hipGetLastError();
+}
+
+hipError_t unet_timestep_launch(float t, int dim, float* out, hipStream_t s) {
+    if (dim < 2 || dim % 2) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(unet_timestep_kernel, dim3(blocks_for(dim / 2, 256)), dim3(256), 0, s, t, dim, out);
     return hipGetLastError();
 }
 

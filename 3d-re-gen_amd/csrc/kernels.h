@@ -212,6 +212,10 @@ hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const 
 // out(bf16)[r][c] = in[r][c] * gelu_erf(in[r][F + c])   (diffusers GEGLU)
 hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);
+// nearest 2x upsampling: f32 [H][W][C] -> bf16 [2H][2W][C]
+hipError_t upsample2x_launch(const float* x, int H, int W, int C, uint16_t* y, hipStream_t s);
+// diffusers Timesteps(flip_sin_to_cos, freq_shift 0): out f32 [dim] = [cos | sin]
+hipError_t unet_timestep_launch(float t, int dim, float* out, hipStream_t s);
 
 }  // namespace r3g
 #endif

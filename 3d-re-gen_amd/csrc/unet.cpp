@@ -9,8 +9,10 @@
 // Activations are rows: f32 [H*W][C] (the hidden state; a pixel's channels contiguous), GEMM operands bf16.  Every
 // convolution is im2col3x3 (conv_kernels.hip) + the MFMA GEMM of gemm.hip with its fused epilogues (bias, fp32 residual
 // add); a 1x1 convolution is the GEMM itself.  Attention is attn.hip's flash kernel (head dim 64: SD 2.x's heads).
-// What is NOT here yet: conv_in / conv_out, the up blocks, the time-embedding MLP, the VAE, schedulers, and upstream's
-// multiview / reference attention extensions -- the texture stage keeps reporting its `texture_source` (stage/run.py).
+// r3g_unet_forward strings them into the whole UNet2DConditionModel.forward of the SD-2.1 layout (conv_in, time embedding,
+// down path with skip connections, mid block, up path on cat(hidden, skip) with nearest upsampling, conv_norm_out, conv_out).
+// What is NOT here yet: the VAE, the schedulers, the text / image encoders, and upstream's multiview / reference attention
+// extensions of this UNet -- the texture stage keeps reporting its `texture_source` (stage/run.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -46,6 +48,11 @@ struct Unet {
     uint16_t *ctxK = nullptr, *ctxVt = nullptr;
     float *vec = nullptr;                  // [4][max_channels] small vectors
     double* gn_partial = nullptr;
+    // whole-model forward (r3g_unet_forward): the concatenated input of an up-block resnet, two hidden-state buffers, the
+    // time embedding, and the stack of skip connections (allocated on first use for the resolution at hand)
+    float *catbuf = nullptr, *hb[2] = {nullptr, nullptr}, *emb = nullptr;
+    float* skips = nullptr;
+    size_t skips_bytes = 0;
 };
 
 #define U_TRY(expr)                                            \
@@ -258,16 +265,137 @@ static int unet_downsample(Unet& u, const std::string& pre, const float* x, int 
     return u_conv3x3(u, u.xn, H, W, C, 2, cv, cv.b, out, EPI_F32, s);
 }
 
+// diffusers Upsample2D: nearest 2x, then conv 3x3 (padding 1)
+static int unet_upsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s) {
+    U_RC(u_check_shape(u, 2 * H, 2 * W, C, "r3g_unet_upsample"));
+    ULin cv;
+    U_RC(u_lin(u, pre + ".conv", true, C, 9 * C, &cv));
+    U_TRY(upsample2x_launch(x, H, W, C, u.xn, s));
+    return u_conv3x3(u, u.xn, 2 * H, 2 * W, C, 1, cv, cv.b, out, EPI_F32, s);
+}
+
+// diffusers UNet2DConditionModel.forward on the SD-2.1 layout: conv_in, time embedding, CrossAttnDownBlock2D x (n-1) +
+// DownBlock2D, UNetMidBlock2DCrossAttn, UpBlock2D + CrossAttnUpBlock2D x (n-1) (every resnet of the up path takes
+// cat(hidden, skip)), conv_norm_out + SiLU + conv_out.  sample f32 [H*W][in_channels] -> out f32 [H*W][out_channels].
+static int unet_forward(Unet& u, const float* sample, int H, int W, float timestep, const uint16_t* ctx, int tokens, float* out,
+                        hipStream_t s) {
+    const r3g_unet_config& c = u.c;
+    const int n = c.n_levels, L = c.layers_per_block;
+    if (n < 1 || n > 4 || L < 1) return fail(R3G_ERR_STATE, "r3g_unet_forward: the configuration has no block structure");
+    if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) return fail(R3G_ERR_INVALID, "r3g_unet_forward: %d x %d is not divisible by %d", H, W, 1 << (n - 1));
+    const int* ch = c.block_out_channels;
+    const int c0 = ch[0];
+    U_RC(u_check_shape(u, H, W, c0, "r3g_unet_forward"));
+    // skip stack: conv_in output + every state of the down path
+    struct Skip { float* p; int c, h, w; };
+    std::vector<Skip> stack;
+    {
+        size_t need = 0;
+        int h = H, w = W;
+        need += (size_t)h * w * c0;
+        for (int i = 0; i < n; ++i) {
+            need += (size_t)L * h * w * ch[i];
+            if (i < n - 1) { h /= 2; w /= 2; need += (size_t)h * w * ch[i]; }
+        }
+        need *= 4;
+        if (need > u.skips_bytes) {
+            if (u.skips) { U_TRY(hipStreamSynchronize(s)); (void)hipFree(u.skips); u.skips = nullptr; u.skips_bytes = 0; }
+            U_TRY(hipMalloc((void**)&u.skips, need));
+            u.skips_bytes = need;
+        }
+    }
+    float* next_slot = u.skips;
+    auto push = [&](int cc, int h, int w) { Skip k{next_slot, cc, h, w}; next_slot += (size_t)h * w * cc; stack.push_back(k); return k.p; };
+    // time embedding: Timesteps(c0) -> linear_1 -> SiLU -> linear_2
+    ULin l1, l2;
+    U_RC(u_lin(u, "time_embedding.linear_1", true, c.temb_dim, c0, &l1));
+    U_RC(u_lin(u, "time_embedding.linear_2", true, c.temb_dim, c.temb_dim, &l2));
+    float* tsin = u.emb + c.temb_dim;   // [c0] sinusoidal features; linear_1's output goes through u.t1 (free here)
+    U_TRY(unet_timestep_launch(timestep, c0, tsin, s));
+    U_TRY(gemv_launch(tsin, 1, c0, l1.w, l1.K, l1.b, u.t1 /* scratch */, c.temb_dim, 0, 1, s));
+    U_TRY(gemv_launch(u.t1, 1, c.temb_dim, l2.w, l2.K, l2.b, u.emb, c.temb_dim, 0, 0, s));
+    // conv_in (input channels zero-padded to 64 in the operand and in the re-laid weight)
+    {
+        ULin ci;
+        U_RC(u_lin(u, "conv_in", true, c0, 9 * 64, &ci));
+        if (c.in_channels < 1 || c.in_channels > 64) return fail(R3G_ERR_INVALID, "r3g_unet_forward: in_channels must be in [1, 64]");
+        U_TRY(cast_pad_launch(sample, c.in_channels, u.xn, 64, H * W, c.in_channels, 64, 1.0f, s));
+        float* x0 = push(c0, H, W);
+        U_RC(u_conv3x3(u, u.xn, H, W, 64, 1, ci, ci.b, x0, EPI_F32, s));
+    }
+    const float* cur = stack.back().p;
+    int h = H, w = W, cc = c0;
+    for (int i = 0; i < n; ++i) {
+        const bool last = i == n - 1;
+        const std::string pre = "down_blocks." + std::to_string(i);
+        for (int j = 0; j < L; ++j) {
+            float* dst = push(ch[i], h, w);
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), cur, h, w, cc, ch[i], u.emb, dst, s));
+            if (!last) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), dst, h, w, ch[i], ctx, tokens, s));
+            cur = dst;
+            cc = ch[i];
+        }
+        if (!last) {
+            float* dst = push(cc, h / 2, w / 2);
+            U_RC(unet_downsample(u, pre + ".downsamplers.0", cur, h, w, cc, dst, s));
+            cur = dst;
+            h /= 2; w /= 2;
+        }
+    }
+    // mid block
+    int side = 0;
+    U_RC(unet_resnet(u, "mid_block.resnets.0", cur, h, w, cc, cc, u.emb, u.hb[side], s));
+    U_RC(unet_transformer(u, "mid_block.attentions.0", u.hb[side], h, w, cc, ctx, tokens, s));
+    U_RC(unet_resnet(u, "mid_block.resnets.1", u.hb[side], h, w, cc, cc, u.emb, u.hb[side], s));
+    cur = u.hb[side];
+    // up path
+    for (int i = 0; i < n; ++i) {
+        const int cout = ch[n - 1 - i];
+        const std::string pre = "up_blocks." + std::to_string(i);
+        for (int j = 0; j <= L; ++j) {
+            if (stack.empty()) return fail(R3G_ERR_STATE, "r3g_unet_forward: skip stack underflow");
+            const Skip sk = stack.back();
+            stack.pop_back();
+            if (sk.h != h || sk.w != w) return fail(R3G_ERR_STATE, "r3g_unet_forward: skip resolution mismatch");
+            const int cin = cc + sk.c;
+            if (cin > c.max_channels) return fail(R3G_ERR_INVALID, "r3g_unet_forward: %d concatenated channels exceed max_channels", cin);
+            const size_t hwn = (size_t)h * w;
+            U_TRY(hipMemcpy2DAsync(u.catbuf, (size_t)cin * 4, cur, (size_t)cc * 4, (size_t)cc * 4, hwn, hipMemcpyDeviceToDevice, s));
+            U_TRY(hipMemcpy2DAsync(u.catbuf + cc, (size_t)cin * 4, sk.p, (size_t)sk.c * 4, (size_t)sk.c * 4, hwn, hipMemcpyDeviceToDevice, s));
+            side ^= 1;
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), u.catbuf, h, w, cin, cout, u.emb, u.hb[side], s));
+            if (i > 0) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), u.hb[side], h, w, cout, ctx, tokens, s));
+            cur = u.hb[side];
+            cc = cout;
+        }
+        if (i < n - 1) {
+            side ^= 1;
+            U_RC(unet_upsample(u, pre + ".upsamplers.0", cur, h, w, cc, u.hb[side], s));
+            cur = u.hb[side];
+            h *= 2; w *= 2;
+        }
+    }
+    // conv_norm_out + SiLU + conv_out
+    const float *gw, *gb;
+    U_RC(u_vec(u, "conv_norm_out.weight", c0, &gw));
+    U_RC(u_vec(u, "conv_norm_out.bias", c0, &gb));
+    ULin co;
+    U_RC(u_lin(u, "conv_out", true, c.out_channels, 9 * c0, &co));
+    U_TRY(group_norm_launch(cur, H * W, c0, c.groups, gw, gb, 1e-5f, 1, u.xn, u.gn_partial, s));
+    return u_conv3x3(u, u.xn, H, W, c0, 1, co, co.b, out, EPI_F32, s);
+}
+
 static void unet_free(Unet* u) {
     if (!u) return;
     if (u->arena) (void)hipFree(u->arena);
+    if (u->skips) (void)hipFree(u->skips);
     delete u;
 }
 
 static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     if (ctx->unet) { unet_free((Unet*)ctx->unet); ctx->unet = nullptr; }
     const r3g_unet_config& c = *cfg;
-    if (c.max_hw < 1 || c.max_channels < 64 || c.max_channels % 64 || c.max_channels > 2048 || c.temb_dim < 1 || c.temb_dim % 8 ||
+    if (c.max_hw < 1 || c.max_channels < 64 || c.max_channels % 64 || c.max_channels > 3072 || c.temb_dim < 1 || c.temb_dim % 8 ||
         c.ctx_dim % 64 || c.ctx_tokens < 1 || c.groups < 1 || c.groups > 256)
         return fail(R3G_ERR_INVALID, "r3g_unet_create: bad configuration");
     Unet* u = new Unet();
@@ -279,7 +407,8 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
                  o_q = carve(heads * hwp * 64 * 2), o_k = carve(heads * hwp * 64 * 2), o_v = carve(heads * hwp * 64 * 2),
                  o_att = carve(hw * C * 2), o_ff = carve(hw * 8 * C * 2), o_ff2 = carve(hw * 4 * C * 2),
                  o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
-                 o_gn = carve(256LL * 256 * 2 * 8);
+                 o_gn = carve(256LL * 256 * 2 * 8), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
+                 o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4);
     hipError_t e = hipMalloc((void**)&u->arena, off);
     if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMalloc(unet arena)"); }
     e = hipMemset(u->arena, 0, off);      // padded rows must start finite
@@ -289,6 +418,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     u->Q = (uint16_t*)(a + o_q); u->K = (uint16_t*)(a + o_k); u->Vt = (uint16_t*)(a + o_v); u->att = (uint16_t*)(a + o_att);
     u->ff = (uint16_t*)(a + o_ff); u->ff2 = (uint16_t*)(a + o_ff2); u->ctxK = (uint16_t*)(a + o_ck); u->ctxVt = (uint16_t*)(a + o_cv);
     u->vec = (float*)(a + o_vec); u->gn_partial = (double*)(a + o_gn);
+    u->catbuf = (float*)(a + o_cat); u->hb[0] = (float*)(a + o_hb0); u->hb[1] = (float*)(a + o_hb1); u->emb = (float*)(a + o_emb);
     ctx->unet = u;
     return R3G_OK;
 }
@@ -366,6 +496,13 @@ int r3g_unet_down_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int 
     }
     if (add_downsample) return unet_downsample(*u, pre + ".downsamplers.0", in, height, width, c_out, d_out, s);
     return R3G_OK;
+}
+
+int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
+                     float* d_out, void* stream) {
+    NEED_UNET("r3g_unet_forward");
+    if (!d_sample || !d_ctx || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_forward: null argument");
+    return unet_forward(*u, d_sample, height, width, timestep, d_ctx, tokens, d_out, (hipStream_t)stream);
 }
 
 int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,

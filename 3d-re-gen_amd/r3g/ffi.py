@@ -63,6 +63,7 @@ SYMBOLS = {
     "r3g_unet_transformer": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _I, _P]),
     "r3g_unet_downsample": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _P]),
     "r3g_unet_down_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "r3g_unet_forward": (_I, [_P, _P, _I, _I, ctypes.c_float, _P, _I, _P, _P]),
     "r3g_unet_mid_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
     "r3g_op_quant_fp8": (_I, [_P, ctypes.c_int64, _I, _I, _P, ctypes.c_int64, _P, _P]),
@@ -90,7 +91,8 @@ class ModelConfig(ctypes.Structure):
 class UnetConfig(ctypes.Structure):
     """struct r3g_unet_config (include/r3g.h)"""
     _fields_ = [(n, ctypes.c_int32) for n in ("max_hw", "max_channels", "temb_dim", "ctx_dim", "ctx_tokens", "groups")] + [
-        ("resnet_eps", ctypes.c_float)]
+        ("resnet_eps", ctypes.c_float)] + [(n, ctypes.c_int32) for n in ("n_levels", "layers_per_block", "in_channels", "out_channels")] + [
+        ("block_out_channels", ctypes.c_int32 * 4)]
 
 
 _LIB = None

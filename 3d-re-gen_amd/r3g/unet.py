@@ -28,7 +28,14 @@ def prepare_weights(sd, device):
                 out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
             continue
         if t.ndim == 4:
-            t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1) if t.shape[-1] == 3 else t.reshape(t.shape[0], t.shape[1])
+            if t.shape[-1] == 3:
+                t = t.permute(0, 2, 3, 1)                      # [O][ky][kx][I]
+                if t.shape[-1] % 64:                           # conv_in: its few input channels are zero-padded to 64
+                    pad = torch.zeros(t.shape[:3] + (64 - t.shape[-1] % 64,), dtype=t.dtype)
+                    t = torch.cat([t, pad], dim=-1)
+                t = t.reshape(t.shape[0], -1)
+            else:
+                t = t.reshape(t.shape[0], t.shape[1])
         if t.ndim == 2:
             out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
         else:
@@ -55,14 +62,19 @@ def from_rows(r, h, w):
 
 
 class UnetBlocks:
-    def __init__(self, state_dict, max_hw, max_channels, temb_dim, ctx_dim, ctx_tokens, groups=32, resnet_eps=1e-5, device=0):
+    def __init__(self, state_dict, max_hw, max_channels, temb_dim, ctx_dim, ctx_tokens, groups=32, resnet_eps=1e-5, device=0,
+                 block_out_channels=(), layers_per_block=2, in_channels=4, out_channels=4):
+        """block_out_channels: the level structure for forward() (empty: building blocks only); max_channels must then cover
+        the widest cat(hidden, skip) of the up path (2 x the widest level)"""
         if not torch.cuda.is_available():
             raise RuntimeError("r3g.unet needs an MI355X: libr3g has no CPU path")
         self.device = torch.device("cuda", device)
         self.ctx = _l.new_context(device)          # a context of its own: the shape model keeps the shared one
         self.L = _l.lib()
         c = _l.UnetConfig(int(max_hw), int(max_channels), int(temb_dim), int(ctx_dim), int(ctx_tokens), int(groups),
-                          float(resnet_eps))
+                          float(resnet_eps), len(block_out_channels), int(layers_per_block), int(in_channels), int(out_channels),
+                          (ctypes.c_int32 * 4)(*(list(block_out_channels) + [0] * (4 - len(block_out_channels)))))
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_unet_create(self.ctx, ctypes.byref(c)))
             self._w = prepare_weights(state_dict, self.device)
@@ -121,6 +133,17 @@ class UnetBlocks:
             o = from_rows(out, ho, wo)
             return o, st + [o]
         return st[-1], st
+
+    def forward(self, sample, timestep, ctx):
+        """UNet2DConditionModel.forward: sample NCHW [1, in_channels, H, W], scalar timestep, ctx [1, tokens, ctx_dim] ->
+        NCHW [1, out_channels, H, W]"""
+        _, cin, h, w = sample.shape
+        rows, _, cx = self._in(sample, None, ctx)
+        out = torch.empty((h * w, self.out_channels), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_forward(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), cx.data_ptr(),
+                                             cx.shape[0], out.data_ptr(), self._s()))
+        return from_rows(out, h, w)
 
     def mid_block(self, prefix, x, temb, ctx):
         _, c, h, w = x.shape

@@ -229,8 +229,9 @@ int r3g_grid_query(r3g_ctx* ctx, double bound, int octree_resolution, float* d_g
  * src/2d_to_3d_models/run.py:97; built at :126-128, :207-209) are diffusers UNet2DConditionModels on the Stable-Diffusion-2.1
  * layout.  These entry points are their building blocks on gfx950 -- ResnetBlock2D, Transformer2DModel
  * (use_linear_projection, one BasicTransformerBlock: self-attention, cross-attention over the context, GEGLU feed-forward),
- * Downsample2D, and the compositions CrossAttnDownBlock2D / UNetMidBlock2DCrossAttn; conv_in / conv_out, the up blocks, the
- * VAE and the schedulers are NOT part of this library yet (the stage keeps reporting where its colours come from).
+ * Downsample2D / Upsample2D, the compositions CrossAttnDownBlock2D / UNetMidBlock2DCrossAttn, and the whole
+ * UNet2DConditionModel.forward (r3g_unet_forward); the VAE, the schedulers, the context encoders and upstream's multiview /
+ * reference attention extensions are NOT part of this library yet (the stage keeps reporting where its colours come from).
  * Activations are rows: f32 [height*width][channels] (NHWC: a pixel's channels contiguous; channels % 64 == 0, head dim
  * 64), the context bf16 [tokens][ctx_dim], the time embedding f32 [temb_dim] (the output of the UNet's time_embedding MLP).
  * Weights are registered under diffusers' state-dict names below `prefix` ("down_blocks.0", "mid_block", ...):
@@ -246,6 +247,10 @@ typedef struct r3g_unet_config {
     int32_t ctx_tokens;     /* most context tokens (77 for CLIP text) */
     int32_t groups;         /* norm_num_groups: 32 */
     float resnet_eps;       /* GroupNorm eps of the resnets: 1e-5 (Transformer2DModel's norm uses 1e-6, its LayerNorms 1e-5) */
+    /* block structure, for r3g_unet_forward only (0 levels: building blocks only): SD 2.1 = 4 levels (320, 640, 1280, 1280),
+     * 2 layers per block, 4 -> 4 channels.  max_channels must cover the widest concatenation of the up path (2560) */
+    int32_t n_levels, layers_per_block, in_channels, out_channels;
+    int32_t block_out_channels[4];
 } r3g_unet_config;
 int r3g_unet_create(r3g_ctx* ctx, const r3g_unet_config* cfg);
 int r3g_unet_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols);
@@ -263,6 +268,12 @@ int r3g_unet_downsample(r3g_ctx* ctx, const char* prefix, const float* d_x, int 
 int r3g_unet_down_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int c_in, int c_out,
                         const float* d_temb, const uint16_t* d_ctx, int tokens, int layers, int add_downsample, float* d_states,
                         float* d_out, void* stream);
+/* UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states) on the SD-2.1 layout (CrossAttnDownBlock2D x (n-1) +
+ * DownBlock2D | UNetMidBlock2DCrossAttn | UpBlock2D + CrossAttnUpBlock2D x (n-1); conv_in / time_embedding / conv_norm_out /
+ * conv_out under diffusers' names; "conv_in.weight" registered with its input channels zero-padded to 64):
+ * d_sample f32 [height*width][in_channels] -> d_out f32 [height*width][out_channels]; height, width divisible by 2^(n-1). */
+int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
+                     float* d_out, void* stream);
 /* UNetMidBlock2DCrossAttn.forward: resnet, transformer, resnet -> d_out f32 [height*width][channels] */
 int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,
                        const float* d_temb, const uint16_t* d_ctx, int tokens, float* d_out, void* stream);

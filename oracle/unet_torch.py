@@ -168,6 +168,117 @@ class UNetMidBlock2DCrossAttn(nn.Module):
         return x
 
 
+class DownBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, layers=2, groups=32, add_downsample=True):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, groups) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_downsample else None
+
+    def forward(self, x, temb, ctx=None):
+        states = []
+        for r in self.resnets:
+            x = r(x, temb)
+            states.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            states.append(x)
+        return x, states
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class UpBlock2D(nn.Module):
+    """diffusers get_up_block: resnet j takes cat(hidden, skip) with skip channels = in_channels for the last resnet,
+    out_channels otherwise; hidden channels = prev_output_channel for the first resnet, out_channels otherwise"""
+
+    def __init__(self, cin, cout, cprev, temb_dim, heads=None, ctx_dim=None, layers=3, groups=32, add_upsample=True):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D((cprev if j == 0 else cout) + (cin if j == layers - 1 else cout), cout,
+                                                    temb_dim, groups) for j in range(layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, ctx_dim, groups) for _ in range(layers)]) \
+            if heads is not None else None
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
+
+    def forward(self, x, skips, temb, ctx=None):
+        for j, r in enumerate(self.resnets):
+            x = r(torch.cat([x, skips[-1 - j]], dim=1), temb)
+            if self.attentions is not None:
+                x = self.attentions[j](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+def timestep_embedding(t, dim):
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]"""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = t.float()[:, None] * freqs[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class UNet2DConditionModel(nn.Module):
+    """diffusers UNet2DConditionModel on the SD-2.1 layout: CrossAttnDownBlock2D x (n-1) + DownBlock2D, mid block,
+    UpBlock2D + CrossAttnUpBlock2D x (n-1); parameter names are diffusers' (conv_in, time_embedding.linear_1, down_blocks.i...,
+    up_blocks.i.upsamplers.0.conv, conv_norm_out, conv_out)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        ch, heads, L, G = cfg["block_out_channels"], cfg["heads"], cfg["layers_per_block"], cfg["groups"]
+        T, X = cfg["temb_dim"], cfg["cross_attention_dim"]
+        n = len(ch)
+        self.conv_in = nn.Conv2d(cfg.get("in_channels", 4), ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], T)
+        downs = []
+        for i in range(n):
+            cin, cout, last = (ch[i - 1] if i else ch[0]), ch[i], i == n - 1
+            downs.append(DownBlock2D(cin, cout, T, L, G, add_downsample=False) if last else
+                         CrossAttnDownBlock2D(cin, cout, T, heads[i], X, L, G, add_downsample=True))
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = UNetMidBlock2DCrossAttn(ch[-1], T, heads[-1], X, G)
+        rch, rheads = list(reversed(ch)), list(reversed(heads))
+        ups, prev = [], rch[0]
+        for i in range(n):
+            cout, cin = rch[i], rch[min(i + 1, n - 1)]
+            ups.append(UpBlock2D(cin, cout, prev, T, None if i == 0 else rheads[i], X, L + 1, G, add_upsample=i < n - 1))
+            prev = cout
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = nn.GroupNorm(G, ch[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(ch[0], cfg.get("out_channels", 4), 3, padding=1)
+
+    def forward(self, sample, timestep, ctx):
+        emb = self.time_embedding(timestep_embedding(torch.as_tensor([float(timestep)]), self.cfg["block_out_channels"][0]))
+        x = self.conv_in(sample)
+        skips = [x]
+        for b in self.down_blocks:
+            x, st = b(x, emb, ctx)
+            skips += st
+        x = self.mid_block(x, emb, ctx)
+        for b in self.up_blocks:
+            k = len(b.resnets)
+            x = b(x, skips[-k:], emb, ctx)
+            skips = skips[:-k]
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
 class UNetSlice(nn.Module):
     """first down block + the mid block of the UNet, under diffusers' names (down_blocks.0.*, mid_block.*): the slice the
     HIP path implements so far.  (conv_in, the other down / up blocks, conv_out: not on the HIP path yet.)"""
@@ -182,10 +293,11 @@ class UNetSlice(nn.Module):
         self.mid_block = UNetMidBlock2DCrossAttn(cm, cfg["temb_dim"], cfg["heads"][-1], cfg["cross_attention_dim"], cfg["groups"])
 
 
-def synthetic_state_dict(cfg, seed=0):
-    """unit-scale weights: every branch moves its residual stream by O(0.3 .. 1) (as oracle/hy3d_torch.py's 'unit' init)"""
+def synthetic_state_dict(cfg, seed=0, full=False):
+    """unit-scale weights: every branch moves its residual stream by O(0.3 .. 1) (as oracle/hy3d_torch.py's 'unit' init);
+    full: the whole UNet2DConditionModel instead of the first-down-block + mid-block slice"""
     g = torch.Generator().manual_seed(seed)
-    m = UNetSlice(cfg)
+    m = UNet2DConditionModel(cfg) if full else UNetSlice(cfg)
     sd = {}
     for k, v in m.state_dict().items():
         if v.ndim >= 2:
@@ -198,7 +310,7 @@ def synthetic_state_dict(cfg, seed=0):
     return sd
 
 
-def load(cfg, sd):
-    m = UNetSlice(cfg)
+def load(cfg, sd, full=False):
+    m = UNet2DConditionModel(cfg) if full else UNetSlice(cfg)
     m.load_state_dict(sd, strict=True)
     return m.eval()

@@ -116,3 +116,40 @@ def test_down_and_mid_block_shapes(small):
         assert m.mid_block(xm, temb, ctx).shape == (1, 128, 4, 4)
         # every branch moves the stream (unit-scale weights): the GPU parity test cannot pass on an identity
         assert float((states[0] - x).norm() / x.norm()) > 0.3
+
+
+def test_full_unet_matches_the_published_parameter_count():
+    """the restated UNet2DConditionModel at SD-2.1 dims has the 865.9 M parameters of stabilityai/stable-diffusion-2-1's unet
+    (a structural pin of the block layout, channel plan and skip wiring: a wrong concat width or a missing block changes it)"""
+    m = U.UNet2DConditionModel(U.sd21_config())
+    n = sum(p.numel() for p in m.parameters())
+    assert n == 865910724
+    sd = m.state_dict()
+    assert sd["up_blocks.1.resnets.0.conv1.weight"].shape == (1280, 2560, 3, 3)      # cat(hidden 1280, skip 1280)
+    assert sd["up_blocks.3.resnets.2.conv1.weight"].shape == (320, 640, 3, 3)        # cat(hidden 320, skip 320: conv_in's output)
+    assert sd["up_blocks.2.resnets.2.conv1.weight"].shape == (640, 960, 3, 3)        # cat(hidden 640, skip 320)
+    assert "up_blocks.0.attentions.0.norm.weight" not in sd and "down_blocks.3.attentions.0.norm.weight" not in sd
+    assert "up_blocks.3.upsamplers.0.conv.weight" not in sd and "up_blocks.0.upsamplers.0.conv.weight" in sd
+
+
+def test_full_unet_forward_small():
+    cfg = U.small_config()
+    sd = U.synthetic_state_dict(cfg, 2, full=True)
+    m = U.load(cfg, sd, full=True)
+    g = torch.Generator().manual_seed(3)
+    x, ctx = torch.randn(1, 4, 16, 12, generator=g), torch.randn(1, 13, cfg["cross_attention_dim"], generator=g)
+    with torch.no_grad():
+        a, b = m(x, 10.0, ctx), m(x, 900.0, ctx)
+    assert a.shape == (1, 4, 16, 12) and torch.isfinite(a).all()
+    assert float((a - b).norm() / a.norm()) > 0.05           # the timestep really enters
+    e = U.timestep_embedding(torch.tensor([3.0]), 8)
+    assert torch.allclose(e[0, :4], torch.cos(3.0 * torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(4) / 4)))
+
+
+def test_conv_in_weight_is_padded_to_64_channels():
+    from r3g import unet as RU
+    w = torch.randn(64, 4, 3, 3)
+    out = RU.prepare_weights({"conv_in.weight": w}, "cpu")["conv_in.weight"][0].float()
+    assert out.shape == (64, 9 * 64)
+    v = out.view(64, 3, 3, 64)
+    assert torch.equal(v[..., :4], w.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and float(v[..., 4:].abs().max()) == 0.0

@@ -41,13 +41,16 @@ def small():
     return Setup(U.small_config(), 3, 24 * 20)
 
 
-def _check(name, got, ref, base=None):
+TOL_MODEL = 2e-2      # a whole UNet forward: ~60 GEMM-backed layers deep
+
+
+def _check(name, got, ref, base=None, tol=TOL):
     import torch
     got = got.cpu()
     assert torch.isfinite(got).all()
     err = rel_l2(got - base, ref - base) if base is not None else rel_l2(got, ref)
-    report(name, err, TOL)
-    assert err <= TOL, (name, err)
+    report(name, err, tol)
+    assert err <= tol, (name, err)
 
 
 @pytest.mark.parametrize("h,w", [(8, 8), (24, 20), (5, 7)])
@@ -146,3 +149,49 @@ def test_unet_errors():
     x, temb, ctx = s.inputs(64, 4, 4, 1)
     with pytest.raises(ffi.R3GError):
         s.gpu.resnet("down_blocks.9.resnets.0", x, temb, 64)      # no such weights
+
+
+def _full(cfg, seed, h, w):
+    import torch
+    from oracle import unet_torch as U
+    from r3g import unet as RU
+    sd = _round(U.synthetic_state_dict(cfg, seed=seed, full=True))
+    oracle = U.load(cfg, sd, full=True)
+    ch = cfg["block_out_channels"]
+    gpu = RU.UnetBlocks(sd, max_hw=h * w, max_channels=2 * max(ch), temb_dim=cfg["temb_dim"], ctx_dim=cfg["cross_attention_dim"],
+                        ctx_tokens=cfg["ctx_tokens"], groups=cfg["groups"], block_out_channels=ch,
+                        layers_per_block=cfg["layers_per_block"])
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(1, 4, h, w, generator=g)
+    ctx = torch.randn(1, cfg["ctx_tokens"], cfg["cross_attention_dim"], generator=g).to(torch.bfloat16).float()
+    return oracle, gpu, x, ctx
+
+
+@pytest.mark.parametrize("h,w,t", [(16, 12, 37.0), (8, 8, 981.0)])
+def test_full_unet_forward_small(h, w, t):
+    """UNet2DConditionModel.forward end to end (conv_in, time embedding, down path with skips, mid block, up path with
+    cat(hidden, skip) and nearest upsampling, conv_norm_out + conv_out) on the two-level CI configuration"""
+    import torch
+    from oracle import unet_torch as U
+    oracle, gpu, x, ctx = _full(U.small_config(), 5, h, w)
+    with torch.no_grad():
+        ref = oracle(x, t, ctx)
+    _check("unet small full forward %dx%d t=%g" % (h, w, t), gpu.forward(x, t, ctx), ref, tol=TOL_MODEL)
+
+
+def test_full_unet_forward_sd21_dims():
+    """the whole SD-2.1-dims UNet (865.9 M parameters, 4 levels, 64x64 latent, 77 x 1024 context), one forward"""
+    import time
+    import torch
+    from oracle import unet_torch as U
+    oracle, gpu, x, ctx = _full(U.sd21_config(), 11, 64, 64)
+    with torch.no_grad():
+        ref = oracle(x, 500.0, ctx)
+    out = gpu.forward(x, 500.0, ctx)
+    _check("unet SD-2.1 dims full forward 64x64", out, ref, tol=TOL_MODEL)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gpu.forward(x, 500.0, ctx)
+    torch.cuda.synchronize()
+    report("unet SD-2.1 dims full forward: milliseconds per evaluation", (time.perf_counter() - t0) / 3 * 1e3, 1e9)
