@@ -214,3 +214,12 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert d["value"] / c["value"] > 100        # the device path is not the oracle in disguise
+    if os.path.basename(files[-1]) >= "r03_bench.json":
+        # round 3: the timed object's mesh was checked against the C marching-cubes oracle inside the run, the HBM-bound
+        # kernel family has its own roofline entry, the counter record says whether it belongs to the library that ran
+        assert d["mc_parity"] == "exact"
+        m = d["roofline_mc"]
+        assert m["bound"] == "hbm" and m["unit"] == "GB/s" and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-9 and 0 < m["frac"] < 1
+        assert m["object_like_field"]["frac"] > m["frac"]
+        assert r["traffic_stale"] in (True, False) and d["config"]["objects_per_launch"] >= 1
+        assert d["steps"] % 1 == 0 and d["config"]["objects_total"] == d["steps"]
