@@ -307,7 +307,7 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
                     print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
                     status.append((i, image_paths[i], "error: %s" % err, secs, rank))
             claimed = []
-    except BaseException as e:      # rank-level failure: keep what is finished, report what was in flight, stay collective
+    except Exception as e:      # rank-level failure: keep what is finished, report what was in flight, stay collective
         rank_error = e
         print("ERROR on rank %d (rank-level, outside the per-object handling): %r" % (rank, e), file=sys.stderr)
         done = {s[0] for s in status}
