@@ -8,7 +8,8 @@ UV texture -> inpaint what no view saw (`mesh_processor.meshVerticeInpaint` + cv
 
 What exists here (partial): everything EXCEPT the two diffusion models.  The native pieces run as HIP
 kernels behind the C ABI (r3g.texops: rasterise, interpolate, view weights, fixed-point baking, vertex-propagation
-inpainting); the unwrap is a per-face chart atlas (r3g.uvatlas).  The views that get baked are
+inpainting); the unwrap is r3g.uvatlas.chart_atlas (axis-projected height-field charts at uniform texel density; the per-face
+atlas of rounds 1-2 remains as `atlas="face"`).  The views that get baked are
   * the views a caller-supplied `multiview_model(image, views) -> list of RGB images` produces, when one is given, or
   * by default ONLY the input image, registered to the front view of the mesh (its alpha silhouette against the mesh
     silhouette); every texel no view saw is filled by colour propagation over the mesh.
@@ -42,7 +43,7 @@ class Hunyuan3DPaintPipeline:
     implemented = True
 
     def __init__(self, texture_size=None, render_size=None, multiview_model=None, views=None, cos_threshold=0.1,
-                 depth_edge=0.02, power=4.0, dilate_iters=8, device=None):
+                 depth_edge=0.02, power=4.0, dilate_iters=8, device=None, atlas=None):
         # upstream: texture_size 2048, render_size 2048; R3G_TEX_SIZE / R3G_TEX_RENDER override the defaults (tests)
         self.texture_size = int(texture_size or os.environ.get("R3G_TEX_SIZE", 2048))
         self.render_size = int(render_size or os.environ.get("R3G_TEX_RENDER", 1024))
@@ -50,6 +51,9 @@ class Hunyuan3DPaintPipeline:
         self.views = list(views) if views is not None else list(DEFAULT_VIEWS)
         self.cos_threshold, self.depth_edge, self.power = float(cos_threshold), float(depth_edge), float(power)
         self.dilate_iters = int(dilate_iters)
+        self.atlas = atlas or os.environ.get("R3G_TEX_ATLAS", "chart")     # "chart" (default) | "face"
+        if self.atlas not in ("chart", "face"):
+            raise ValueError("atlas must be 'chart' or 'face'")
         self.device = device
         self.last_stats = {}
 
@@ -63,7 +67,7 @@ class Hunyuan3DPaintPipeline:
     def from_pretrained(cls, model_path=None, subfolder=None, **kwargs):
         """upstream loads the delight and multiview diffusion checkpoints here; this path has neither (see module doc)"""
         allowed = ("texture_size", "render_size", "multiview_model", "views", "cos_threshold", "depth_edge", "power",
-                   "dilate_iters", "device")
+                   "dilate_iters", "device", "atlas")
         return cls(**{k: v for k, v in kwargs.items() if k in allowed})
 
     # -- helpers -----------------------------------------------------------------------------------------------------
@@ -98,13 +102,25 @@ class Hunyuan3DPaintPipeline:
         f = np.ascontiguousarray(mesh.faces, np.int32)
         nf = len(f)
         T, R = self.texture_size, self.render_size
-        uv, uv_tri = uvatlas.face_atlas(nf, T)
+        if self.atlas == "chart":
+            try:
+                uv, uv_tri, uv_to_pos, chart = uvatlas.chart_atlas(v, f, T)
+                n_charts = int(chart.max()) + 1
+            except ValueError:          # more charts than the texture has room for: every face its own cell
+                uv = None
+        else:
+            uv = None
+        if uv is None:
+            uv, uv_tri = uvatlas.face_atlas(nf, T)
+            uv_to_pos, n_charts = f.reshape(-1), nf
+        corner_tri = np.arange(3 * nf, dtype=np.int32).reshape(nf, 3)             # per-corner attributes (flat normals)
         e1, e2 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
         fn = np.cross(e1, e2)
         fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
         corner_n = np.repeat(fn.astype(np.float32), 3, axis=0)                    # flat normals, one per face corner
 
         d_f, d_uv, d_uvt = torch.from_numpy(f).to(dev), torch.from_numpy(uv).to(dev), torch.from_numpy(uv_tri).to(dev)
+        d_ct = torch.from_numpy(corner_tri).to(dev)
         rgb, alpha, abox = self._front_image(image)
         if self.multiview_model is not None:
             images = [np.ascontiguousarray(np.asarray(im, np.float32)) for im in self.multiview_model(image, self.views)]
@@ -137,14 +153,14 @@ class Hunyuan3DPaintPipeline:
                 fi, bary = texops.rasterize(d_clip, d_f, R, R)
                 depth = texops.interpolate(d_clip[:, 2:3].contiguous(), d_f, fi, bary)[..., 0]
                 nmap = texops.interpolate(torch.from_numpy(np.ascontiguousarray(sign * (corner_n @ rot.T), np.float32)).to(dev),
-                                          d_uvt, fi, bary)
+                                          d_ct, fi, bary)
                 w = texops.view_weight(fi, depth, nmap, self.cos_threshold, self.depth_edge, vw, self.power)
                 if self.multiview_model is None:
                     w = w * torch.from_numpy((alpha > 0.5).astype(np.float32)).to(dev)   # only what the image actually shows
                 if img.shape[0] != R or img.shape[1] != R:
                     raise ValueError("view images must be %d x %d" % (R, R))
-                # texel-centric: every covered texel looks itself up in this view (UV vertex = face corner)
-                texops.bake_gather(fi_uv, bary_uv, torch.from_numpy(np.ascontiguousarray(clip[f].reshape(-1, 4))).to(dev), d_uvt,
+                # texel-centric: every covered texel looks itself up in this view (clip position of every UV vertex)
+                texops.bake_gather(fi_uv, bary_uv, torch.from_numpy(np.ascontiguousarray(clip[uv_to_pos])).to(dev), d_uvt,
                                    torch.from_numpy(img).to(dev), w, fi, depth, acc, self.depth_edge)
             return texops.bake_finalize(acc)
 
@@ -156,9 +172,10 @@ class Hunyuan3DPaintPipeline:
                                            self.dilate_iters)
         covered = int((fi_uv > 0).sum())
         self.last_stats = {"texels_covered": covered, "texels_painted_by_views": painted,
-                           "texels_coloured": int((mask > 0).sum()), "propagation_rounds": rounds, "source": self.source}
+                           "texels_coloured": int((mask > 0).sum()), "propagation_rounds": rounds, "source": self.source,
+                           "atlas": self.atlas, "charts": n_charts, "uv_vertices": int(len(uv))}
         tex8 = (tex.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).cpu().numpy()
-        out = Mesh(v[f].reshape(-1, 3), uv_tri, uv=uv, texture=tex8)
+        out = Mesh(v[uv_to_pos], uv_tri, uv=uv, texture=tex8)     # a vertex is duplicated only where charts meet
         out.metadata = dict(getattr(mesh, "metadata", {}))
         out.metadata["texture_source"] = self.source
         return out

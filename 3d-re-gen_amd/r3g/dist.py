@@ -144,14 +144,19 @@ class WorkQueue:
         return list(range(first, min(first + k, self.n)))
 
 
-def exchange_json(obj, name="r3g_exchange"):
-    """every rank contributes one JSON-serialisable object; every rank gets the list of all of them (index = rank).
-    Host-side records only (names, status lines): they go through the store, not through a collective."""
+def exchange_json(obj, name="r3g_exchange", dst=None):
+    """every rank contributes one JSON-serialisable object; rank `dst` (None: every rank) gets the list of all of them
+    (index = rank), the others None.  Host-side records only (names, status lines): they go through the store, not through a
+    collective.  Ends with a barrier: the rank that serves the store does not run ahead of a rank that is still reading."""
     rank, world = dist.get_rank(), dist.get_world_size()
     store = side_store()
     key = _next_key(name)
     store.set("%s/%d" % (key, rank), json.dumps(obj))
-    return [json.loads(store.get("%s/%d" % (key, r)).decode()) for r in range(world)]     # get() waits for the key
+    out = None
+    if dst is None or rank == dst:
+        out = [json.loads(store.get("%s/%d" % (key, r)).decode()) for r in range(world)]     # get() waits for the key
+    barrier()
+    return out
 
 
 def share_json(obj, src=0, name="r3g_share"):
@@ -160,7 +165,9 @@ def share_json(obj, src=0, name="r3g_share"):
     key = _next_key(name)
     if dist.get_rank() == src:
         store.set(key, json.dumps(obj))
-    return json.loads(store.get(key).decode())
+    out = json.loads(store.get(key).decode())
+    barrier()       # (as exchange_json: nobody leaves while somebody still reads)
+    return out
 
 
 def all_ok(ok):

@@ -324,7 +324,7 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
             local.append((i, np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32),
                           getattr(mesh, "uv", None), getattr(mesh, "texture", None)))     # textured: uv + PNG source pixels too
     gathered = rdist.gather_meshes(local, dst=0)
-    all_status = rdist.exchange_json(status, name="r3g_stage_status")
+    all_status = rdist.exchange_json(status, name="r3g_stage_status", dst=0)
     if rank != 0:
         return None, None, failed_ranks
     for i in sorted(gathered):
@@ -395,6 +395,7 @@ def main(argv=None, factory=default_factory):
         if failed_ranks:      # a rank-level failure (not a per-object one) is a setup error: non-zero, on every rank
             print("[r3g] rank(s) %s failed outside the per-object handling" % failed_ranks, file=sys.stderr)
             rc = rc or 4
+        rdist.barrier()       # rank 0 serves the side store and writes the files: nobody tears the group down before it is done
     finally:
         rdist.reset()
         dist.destroy_process_group()

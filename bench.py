@@ -412,7 +412,7 @@ def main():
     if bad:
         raise SystemExit("bench.py: the timed object's mesh differs from the marching-cubes oracle's mesh of the same grid")
     if dist is not None:
-        dist.barrier()
+        rdist.barrier()
         dist.destroy_process_group()
 
 

@@ -30,22 +30,28 @@ def _scene(level=4, size=256):
     return v, f, Image.fromarray(img, "RGBA")
 
 
-def test_front_view_projection_lands_where_the_image_says():
+@pytest.mark.parametrize("atlas", ["chart", "face"])
+def test_front_view_projection_lands_where_the_image_says(atlas):
     from hy3dgen.texgen import Hunyuan3DPaintPipeline
     from r3g.mesh import Mesh
     from gltf_validate import validate_glb
     v, f, image = _scene()
-    pipe = Hunyuan3DPaintPipeline(texture_size=1024, render_size=256)
+    pipe = Hunyuan3DPaintPipeline(texture_size=1024, render_size=256, atlas=atlas)
     out = pipe(Mesh(v, f), image=image)
     st = pipe.last_stats
     assert 0.25 * st["texels_covered"] < st["texels_painted_by_views"] < 0.55 * st["texels_covered"]   # the front half, minus grazing angles
     assert st["texels_coloured"] >= st["texels_covered"] and st["propagation_rounds"] >= 2
-    assert out.n_faces == len(f) and out.n_vertices == 3 * len(f) and out.texture.shape == (1024, 1024, 3)
+    assert out.n_faces == len(f) and out.texture.shape == (1024, 1024, 3)
+    if atlas == "face":
+        assert out.n_vertices == 3 * len(f)
+    else:       # six axis charts on a sphere: vertices are duplicated along the seams only, the texture is denser per face
+        assert st["charts"] == 6 and len(v) < out.n_vertices < 1.3 * len(v)
+        assert st["texels_covered"] > 0.45 * 1024 * 1024
     # a front-facing face's texture colour = the image colour at the face centre's projection
     # (sphere of radius 1 registered to the disc: x -> column, y -> row, disc radius 0.4 * 256 px)
     T = 1024
-    cen = out.vertices.reshape(-1, 3, 3).mean(axis=1)
-    uvc = out.uv.reshape(-1, 3, 2).mean(axis=1)
+    cen = out.vertices[out.faces].mean(axis=1)
+    uvc = out.uv[out.faces].mean(axis=1)
     front = cen[:, 2] > 0.6
     col = cen[front, 0] * 0.4 * 256 + 127.5
     row = -cen[front, 1] * 0.4 * 256 + 127.5
