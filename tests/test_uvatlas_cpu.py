@@ -1,5 +1,6 @@
-"""The per-face chart atlas of the texture stage (3d-re-gen_amd/r3g/uvatlas.py; upstream unwraps with xatlas in
-hy3dgen/texgen/utils/uv_warp_utils.py: mesh_uv_wrap): charts must not touch, whatever the face count and texture size."""
+"""The UV unwraps of the texture stage (3d-re-gen_amd/r3g/uvatlas.py; upstream unwraps with xatlas in
+hy3dgen/texgen/utils/uv_warp_utils.py: mesh_uv_wrap): the per-face atlas of rounds 1-2 (charts must not touch, whatever the
+face count and texture size) and the chart-based unwrap of round 3 (valid-unwrap invariants checked with the numpy rasteriser)."""
 import os
 import sys
 
