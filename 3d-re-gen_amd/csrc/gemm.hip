@@ -1709,6 +1709,7 @@ static int g_gemm_waves = 0;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 2, g_num_cu = 256;
 bool g_gemm_splitk = false;      // deterministic split-K for deep-K residual GEMMs on under-filled grids (measured: no gain)
+int g_gemm_persistent_resid = 0;   // experiment switch (r3g_set_option "gemm_persistent_resid")
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
@@ -1761,8 +1762,11 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             // epilogue but QKV); it needs 160 KiB of LDS per workgroup
             long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
             if (p2.M > 0) tiles += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
+            // read-modify-write epilogues: bit 0 of gemm_persistent_resid admits the fp32 residual form, bit 1 the bf16 one
+            const bool resid_ok = (EPI != EPI_RESID_F32 || (g_gemm_persistent_resid & 1)) &&
+                                  (EPI != EPI_RESID_BF16 || (g_gemm_persistent_resid & 2));
             if (p.K >= 256 && (p2.M == 0 || p2.K >= 256) &&
-                (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && EPI != EPI_RESID_F32 && EPI != EPI_RESID_BF16 && EPI != EPI_F32))) {
+                (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && resid_ok && EPI != EPI_F32))) {
                 const hipError_t e = launch_gemm8p<EPI>(p, p2, g_num_cu, s);
                 if (e != hipErrorNotSupported) return e;
             }
@@ -1790,6 +1794,7 @@ void gemm_set_auto_rule(int rule, int num_cu) {
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
 void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
+void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
 void gemm_set_config(int waves) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;

@@ -87,6 +87,7 @@ void gemm_set_config(int waves);   // tile kernel: 0 automatic | 4 | 8 | 9 | 10 
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs
+void gemm_set_persistent_resid(int mask);   // persistent form also for the fp32 (bit 0) / bf16 (bit 1) residual epilogues
 void gemm_set_persistent(bool on);   // phased kernel walks several tiles per workgroup (default on)
 void gemm_set_phased(bool on);   // 256x256 tiles: phased kernel (default) or the two-stage one
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages

@@ -1239,6 +1239,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_wide_epilogue")) gemm_set_wide_epilogue(value != 0);
     else if (!strcmp(name, "gemm_phased")) gemm_set_phased(value != 0);
     else if (!strcmp(name, "gemm_persistent")) gemm_set_persistent(value != 0);
+    else if (!strcmp(name, "gemm_persistent_resid")) gemm_set_persistent_resid(value);
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
