@@ -26,13 +26,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return *reinterpret_cast<const uint16_t*>(&h);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-// torch.nn.functional.gelu (exact): erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), as the GEMM epilogue's
+// torch.nn.functional.gelu (exact), x Phi(x) with erfc by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): the GEMM epilogue's form
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.7071067811865476f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.7071067811865476f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
+    const float h = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f)))) * e;
+    return x * (x >= 0.f ? 1.0f - h : h);
 }
 inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 

@@ -37,20 +37,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __expf(2.0f * u);  // tanh(u) = 1 - 2/(e^{2u}+1)
-    const float th = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + th);
+    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as x sigmoid(2u) =
+    // x / (1 + 2^(x (c1 + c3 x^2))): 4 plain VALU + v_exp_f32 + v_rcp_f32 (round 3; the textbook form took 10 + 2 and lost
+    // relative accuracy in the negative tail to the cancellation in 1 + tanh).  Saturates cleanly: 2^(+inf) -> rcp -> 0.
+    constexpr float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    constexpr float c3 = c1 * 0.044715f;
+    const float z = x * fmaf(x * x, c3, c1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
-// exact-form GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step)
+// exact-form GELU, x Phi(x), with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step):
+// h = erfc(|x| / sqrt 2) / 2 = t (b1 + t (b2 + ...)) 2^(-x^2 log2(e) / 2), Phi = x >= 0 ? 1 - h : h (no cancellation in the tail)
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.7071067811865476f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.7071067811865476f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
+    const float h = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f)))) * e;
+    return x * (x >= 0.f ? 1.0f - h : h);
 }
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
