@@ -57,6 +57,7 @@ static int g_geo_fp8 = 0;   // BASELINE.json configs[3]: geo decoder GEMMs on fp
 constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP hidden: |GELU| up to 28 representable
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
+static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached intermediate results (Model::GeoCache) are tied to it
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
 
@@ -118,6 +119,7 @@ struct Model {
         int64_t passes = 0;
         uint16_t *x0 = nullptr, *Q = nullptr;   // [passes][qc][W] each
         std::vector<char> built;
+        unsigned epoch = 0;                     // option epoch the built passes belong to (kernel generations change what Q holds)
         bool refused = false;                   // allocation failed for this (R, bound): do not try again
     } gq;
     std::string err;
@@ -822,6 +824,10 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         }
     }
     use_cache = use_cache && gq.x0 != nullptr;
+    if (use_cache && gq.epoch != g_option_epoch) {      // an option changed since these passes were built: build them again
+        std::fill(gq.built.begin(), gq.built.end(), 0);
+        gq.epoch = g_option_epoch;
+    }
     for (int64_t off = 0; off < count; off += m.qc) {
         const int n = (int)std::min<int64_t>(m.qc, count - off);
         const int npad = (int)rup(n, 128);
@@ -1223,6 +1229,7 @@ int r3g_prof_read_bytes(double* bytes, int n) {
 
 int r3g_set_option(const char* name, int value) {
     if (!name) return fail(R3G_ERR_INVALID, "r3g_set_option: null name");
+    ++g_option_epoch;
     if (!strcmp(name, "fuse_qkv")) g_fuse_qkv = value != 0;
     else if (!strcmp(name, "batch_mods")) g_batch_mods = value != 0;
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;

@@ -371,6 +371,17 @@ def test_query_side_cache_of_the_geo_decoder_is_bit_identical(tiny):
         part.zero_()
         m.grid_query(1.01, R, out=part, start=8192, count=4096 * 3 + 5)   # canonical passes 2..4 from the cache + a fragment
         assert torch.equal(part.reshape(-1)[8192:8192 + 4096 * 3 + 5], ref_b.reshape(-1)[8192:8192 + 4096 * 3 + 5])
+        # an option that changes what the cached Q rows hold (generation 1 kernels take a plain Q, the default ones a
+        # pre-scaled Q): the passes built before the switch must not be served after it
+        try:
+            ffi.check(L.r3g_set_option(b"attn_generation", 1))
+            with_stale_risk = m.grid_query(1.01, R).clone()
+            ffi.check(L.r3g_set_option(b"geo_q_cache", 0))
+            assert torch.equal(m.grid_query(1.01, R), with_stale_risk)
+        finally:
+            ffi.check(L.r3g_set_option(b"attn_generation", 7))
+            ffi.check(L.r3g_set_option(b"geo_q_cache", 1))
+        assert (with_stale_risk - ref_b).abs().max() <= 2e-2 * ref_b.abs().max()
         # other weights through the same context: the cache of the old ones must not survive
         from oracle import hy3d_torch as H
         sd2 = bf16_round_matrices(H.synthetic_state_dict(tiny.cfg, seed=77))
