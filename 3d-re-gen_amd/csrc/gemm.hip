@@ -150,6 +150,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         const float* nw = type == 0 ? e.qw : e.kw;
         const float* nb = type == 0 ? e.qb : e.kb;
         const bool do_norm = type < 2 && e.norm != QKN_NONE;
+        // the per-column constants of the wave's 64 columns, loaded ONCE: inside the row loop the compiler has to re-load them
+        // after every store (the pointers may alias for all it knows) and waits for them eight times per tile
+        f32x4 bias4[4], nw4[4], nb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            nw4[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            nb4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * 64 + j * 16 + dbase);
+            if (do_norm && nw) nw4[j] = *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase);
+            if (do_norm && e.norm == QKN_LAYERNORM && nb) nb4[j] = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wr * WROWS + i * 16 + (lane & 15);
@@ -157,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = acc[j][i];
-                if (p.bias) v[j] += *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * 64 + j * 16 + dbase);
+                if (p.bias) v[j] += bias4[j];
             }
             if (do_norm) {
                 float mean = 0.f;
@@ -178,12 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 s2 += __shfl_xor(s2, 32, 64);
                 const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 w = nw ? *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase) : (f32x4){1.f, 1.f, 1.f, 1.f};
-                    f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (e.norm == QKN_LAYERNORM && nb) b = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
-                    v[j] = (v[j] - mean) * r * w + b;
-                }
+                for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) * r * nw4[j] + nb4[j];
             }
             if (type == 0 && e.q_scale != 0.f) {   // softmax scale * log2(e) folded into q before the bf16 rounding
 #pragma unroll
