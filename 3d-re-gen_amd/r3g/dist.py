@@ -184,11 +184,12 @@ def all_ok(ok):
 _META = 6   # index, nV, nF, texture shape (3; zeros = no texture)
 
 
-def gather_meshes(local, dst=0):
+def gather_meshes(local, dst=0, to_host=True):
     """local: list of (index, vertices float32 [nV,3], faces int [nF,3]) or (index, vertices, faces, uv float32 [nV,2],
     texture uint8 [T,T,C]) tensors / arrays produced on this rank.
     Returns on rank `dst` a dict index -> (vertices float32 ndarray, faces int32 ndarray[, uv, texture]) of ALL ranks; {}
-    elsewhere."""
+    elsewhere.  to_host=False leaves the arrays as tensors on the communication device (HBM under RCCL): a consumer on the
+    GPU -- or a throughput measurement -- does not pay 20 MB of device-to-host copy per raw mesh."""
     dev = _comm_device()
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = []
@@ -217,6 +218,8 @@ def gather_meshes(local, dst=0):
     meta = [allrows[r][:counts[r]].cpu().tolist() for r in range(world)]
 
     def pack(v, f, uv, tex):
+        if not to_host:
+            return (v, f) if tex is None else (v, f, uv, tex)
         return (v.cpu().numpy(), f.cpu().numpy()) if tex is None else (v.cpu().numpy(), f.cpu().numpy(), uv.cpu().numpy(),
                                                                       tex.cpu().numpy())
     out = {}

@@ -251,7 +251,7 @@ def main():
     last = meshes[-1] if meshes else None
     if dist is not None:       # the meshes travel to rank 0 over RCCL (point-to-point, variable length)
         made = [(rank + world * (a.warmup + j), m[0], m[1]) for j, m in enumerate(meshes) if m is not None]
-        gathered = rdist.gather_meshes(made, dst=0)
+        gathered = rdist.gather_meshes(made, dst=0, to_host=False)     # the raw meshes stay in rank 0's HBM
         if rank == 0 and len(gathered) != world * a.steps:
             raise SystemExit("gather_meshes returned %d of %d meshes" % (len(gathered), world * a.steps))
         del gathered, made
@@ -279,7 +279,7 @@ def main():
                 break
             ms_ = group([Image.fromarray(dev_crops[i % len(dev_crops)].cpu().numpy(), "RGBA") for i in idx])
             mine += [(i, m[0], m[1]) for i, m in zip(idx, ms_) if m is not None]
-        got = rdist.gather_meshes(mine, dst=0)
+        got = rdist.gather_meshes(mine, dst=0, to_host=False)
         torch.cuda.synchronize()
         barrier()
         ts = torch.tensor([time.perf_counter() - t1], device=rdist._comm_device(), dtype=torch.float64)

@@ -247,6 +247,8 @@ def test_broadcast_crops_and_gather_roundtrip_single_process(tmp_path):
         f = np.array([[0, 1, 2], [0, 2, 3]])
         out = rdist.gather_meshes([(4, torch.from_numpy(v), torch.from_numpy(f)), (1, v[:3], f[:1])])
         assert sorted(out) == [1, 4] and np.array_equal(out[4][0], v) and out[4][1].dtype == np.int32
+        dev = rdist.gather_meshes([(4, torch.from_numpy(v), torch.from_numpy(f))], to_host=False)     # stays a tensor
+        assert isinstance(dev[4][0], torch.Tensor) and torch.equal(dev[4][0], torch.from_numpy(v)) and dev[4][1].dtype == torch.int32
         assert rdist.broadcast_crops([]) == []
     finally:
         dist.destroy_process_group()
