@@ -3,7 +3,7 @@
 // What diffusers executes as cuDNN conv / GroupNorm / SiLU / GEGLU passes (ResnetBlock2D, Transformer2DModel, Downsample2D),
 // here on rows: an activation is f32 or bf16 [H*W][C] (NHWC -- a pixel's channels are contiguous), so that every linear
 // layer AND every convolution is the MFMA GEMM of gemm.hip over those rows:
-//   * im2col3x3   : bf16 [H][W][C] -> bf16 [Ho*Wo][9 C], column (ky*3 + kx)*C + c, zero padding 1, stride 1 | 2; the 3x3
+//   * im2col3x3   : bf16 [H][W][C] -> bf16 [Ho*Wo][9 C], column (ky*3 + kx)*C + c, zero padding 1 (or 0 before / 1 after), stride 1 | 2; the 3x3
 //                   convolution is then C_out = A . W^T with W re-laid to [C_out][ky][kx][C_in] (r3g/unet.py).  16 bytes per
 //                   thread, a wave covers 1 KiB of contiguous output.  (An implicit-GEMM staging path that gathers the nine
 //                   shifted rows straight into LDS would save this matrix's round trip through HBM: next step.)
@@ -35,7 +35,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int stride,
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int stride, int pad,
                                                         int Ho, int Wo, uint16_t* __restrict__ out) {
     const int c8n = C >> 3;
     const int64_t total = (int64_t)Ho * Wo * 9 * c8n;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restri
     const int tap = (int)(r % 9);
     const int64_t m = r / 9;
     const int oy = (int)(m / Wo), ox = (int)(m % Wo);
-    const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+    const int iy = oy * stride + tap / 3 - pad, ix = ox * stride + tap % 3 - pad;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + ((int64_t)iy * W + ix) * C + c8 * 8);
     *reinterpret_cast<uint4*>(out + m * (9 * (int64_t)C) + (int64_t)tap * C + c8 * 8) = v;
@@ -166,6 +166,46 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     *reinterpret_cast<uint2*>(y + m * C + c) = pk;
 }
 
+// softmax over the rows of an fp32 score matrix S [rows][n] (times `scale`) -> bf16 probabilities P [rows][n]: the single-head,
+// head-dim-512 attention of the VAE's mid block is two GEMMs around this (attn.hip's flash kernel is built for head dim 64).
+// One block per row, three sweeps over a row that stays in L2 (n <= 16 384 floats); exp2 with the scale folded into log2(e).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds, uint16_t* __restrict__ P,
+                                                           int64_t ldp, int n, float scale_log2) {
+    __shared__ float red[4];
+    const float* row = S + (int64_t)blockIdx.x * lds;
+    uint16_t* out = P + (int64_t)blockIdx.x * ldp;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float mx = -INFINITY;
+    for (int i = t * 4; i < n; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2;
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = t * 4; i < n; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        sum += __builtin_amdgcn_exp2f(fmaf(v.x, scale_log2, -mx)) + __builtin_amdgcn_exp2f(fmaf(v.y, scale_log2, -mx)) +
+               __builtin_amdgcn_exp2f(fmaf(v.z, scale_log2, -mx)) + __builtin_amdgcn_exp2f(fmaf(v.w, scale_log2, -mx));
+    }
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int i = t * 4; i < n; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(__builtin_amdgcn_exp2f(fmaf(v.x, scale_log2, -mx)) * inv) |
+               ((uint32_t)f2bf(__builtin_amdgcn_exp2f(fmaf(v.y, scale_log2, -mx)) * inv) << 16);
+        pk.y = (uint32_t)f2bf(__builtin_amdgcn_exp2f(fmaf(v.z, scale_log2, -mx)) * inv) |
+               ((uint32_t)f2bf(__builtin_amdgcn_exp2f(fmaf(v.w, scale_log2, -mx)) * inv) << 16);
+        *reinterpret_cast<uint2*>(out + i) = pk;
+    }
+}
+
 // diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): out[dim] = [cos(t f_k) | sin(t f_k)],
 // f_k = exp(-ln(10000) k / (dim/2))
 __global__ void unet_timestep_kernel(float t, int dim, float* __restrict__ out) {
@@ -184,12 +224,15 @@ __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restr
 
 }  // namespace
 
-hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, uint16_t* out, hipStream_t s) {
-    if (C % 8 || (stride != 1 && stride != 2) || H < 1 || W < 1) return hipErrorInvalidValue;
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s) {
+    if (C % 8 || (stride != 1 && stride != 2) || (pad != 0 && pad != 1) || H < 1 || W < 1 || H + pad < 2 || W + pad < 2)
+        return hipErrorInvalidValue;
+    // zero padding: `pad` rows / columns before, one after (pad 1: the symmetric padding of the UNet's convolutions; pad 0: the
+    // F.pad(x, (0, 1, 0, 1)) in front of the stride-2 convolution of the VAE encoder's Downsample2D)
+    const int Ho = (H + pad + 1 - 3) / stride + 1, Wo = (W + pad + 1 - 3) / stride + 1;
     const int64_t total = (int64_t)Ho * Wo * 9 * (C / 8);
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, H, W, C, stride, Ho, Wo, out);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, H, W, C, stride, pad, Ho, Wo, out);
     return hipGetLastError();
 }
 
@@ -236,6 +279,13 @@ hipError_t unet_timestep_launch(float t, int dim, float* out, hipStream_t s) {
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(vec_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t softmax_rows_launch(const float* S, int64_t lds, uint16_t* P, int64_t ldp, int rows, int n, float scale, hipStream_t s) {
+    if (rows < 1 || n < 4 || n % 4 || (lds & 3) || (ldp & 3)) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, P, ldp, n, scale * 1.4426950408889634f);
     return hipGetLastError();
 }
 

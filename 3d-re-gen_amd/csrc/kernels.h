@@ -205,7 +205,7 @@ hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStre
 
 // ------------------------------------------------------------------ UNet blocks of the texture stage (conv_kernels.hip)
 // bf16 [H][W][C] -> bf16 [Ho*Wo][9 C] (column (ky*3 + kx)*C + c; zero padding 1; stride 1 | 2; C % 8 == 0)
-hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, uint16_t* out, hipStream_t s);
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s);
 // GroupNorm (+ SiLU) of f32 rows [rows][C] -> bf16; partial: workspace of group_norm_blocks(rows) * groups * 2 doubles
 int group_norm_blocks(int rows);
 hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
@@ -213,6 +213,8 @@ hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const 
 // out(bf16)[r][c] = in[r][c] * gelu_erf(in[r][F + c])   (diffusers GEGLU)
 hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);
+// P[r][:] = softmax(scale * S[r][:]) as bf16 (fp32 scores in; n % 4 == 0): the VAE mid block's single-head attention
+hipError_t softmax_rows_launch(const float* S, int64_t lds, uint16_t* P, int64_t ldp, int rows, int n, float scale, hipStream_t s);
 // nearest 2x upsampling: f32 [H][W][C] -> bf16 [2H][2W][C]
 hipError_t upsample2x_launch(const float* x, int H, int W, int C, uint16_t* y, hipStream_t s);
 // diffusers Timesteps(flip_sin_to_cos, freq_shift 0): out f32 [dim] = [cos | sin]

@@ -11,10 +11,12 @@
 // add); a 1x1 convolution is the GEMM itself.  Attention is attn.hip's flash kernel (head dim 64: SD 2.x's heads).
 // r3g_unet_forward strings them into the whole UNet2DConditionModel.forward of the SD-2.1 layout (conv_in, time embedding,
 // down path with skip connections, mid block, up path on cat(hidden, skip) with nearest upsampling, conv_norm_out, conv_out).
-// What is NOT here yet: the VAE, the schedulers, the text / image encoders, and upstream's multiview / reference attention
+// The SD-family VAE (AutoencoderKL encode / decode) runs on the same blocks (r3g_aekl_encode / r3g_aekl_decode, below).
+// What is NOT here yet: the text / image encoders, and upstream's multiview / reference attention
 // extensions of this UNet -- the texture stage keeps reporting its `texture_source` (stage/run.py).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -120,14 +122,16 @@ static int u_check_shape(const Unet& u, int H, int W, int C, const char* what) {
 }
 
 // conv 3x3 (pad 1) of bf16 rows src [H*W][Cin] -> epilogue(dst [Ho*Wo][Cout])
+// pad 1: zero padding 1 all round; pad 0: F.pad(x, (0, 1, 0, 1)) (the VAE encoder's stride-2 Downsample2D)
 static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int stride, const ULin& l, const float* bias, void* dst,
-                     int epi, hipStream_t s) {
-    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    U_TRY(im2col3x3_launch(src, H, W, Cin, stride, u.col, s));
+                     int epi, hipStream_t s, int pad = 1) {
+    const int Ho = (H + pad - 2) / stride + 1, Wo = (W + pad - 2) / stride + 1;
+    U_TRY(im2col3x3_launch(src, H, W, Cin, stride, pad, u.col, s));
     return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, Ho * Wo, epi, s);
 }
 
 // diffusers ResnetBlock2D.forward: out = shortcut(x) + conv2(silu(norm2(conv1(silu(norm1(x))) + time_emb_proj(silu(temb)))))
+// (temb == nullptr: the VAE's resnets, which have no time_emb_proj)
 static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, int W, int Cin, int Cout, const float* temb,
                        float* out, hipStream_t s) {
     U_RC(u_check_shape(u, H, W, Cin, "r3g_unet_resnet"));
@@ -141,12 +145,16 @@ static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, i
     ULin c1, c2, tp;
     U_RC(u_lin(u, pre + ".conv1", true, Cout, 9 * Cin, &c1));
     U_RC(u_lin(u, pre + ".conv2", true, Cout, 9 * Cout, &c2));
-    U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
     // per-channel constant of conv1's epilogue: conv1.bias + time_emb_proj(silu(temb))
-    float* tb = u.vec;
-    float* cb = u.vec + u.c.max_channels;
-    U_TRY(gemv_launch(temb, 1, u.c.temb_dim, tp.w, tp.K, tp.b, tb, Cout, 1, 0, s));
-    U_TRY(vec_add_launch(c1.b, tb, cb, Cout, s));
+    const float* cb = c1.b;
+    if (temb) {
+        U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
+        float* tb = u.vec;
+        float* sum = u.vec + u.c.max_channels;
+        U_TRY(gemv_launch(temb, 1, u.c.temb_dim, tp.w, tp.K, tp.b, tb, Cout, 1, 0, s));
+        U_TRY(vec_add_launch(c1.b, tb, sum, Cout, s));
+        cb = sum;
+    }
     U_TRY(group_norm_launch(x, hw, Cin, G, g1, b1, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
     U_RC(u_conv3x3(u, u.xn, H, W, Cin, 1, c1, cb, u.t1, EPI_F32, s));
     U_TRY(group_norm_launch(u.t1, hw, Cout, G, g2, b2, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
@@ -385,6 +393,166 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
     return u_conv3x3(u, u.xn, H, W, c0, 1, co, co.b, out, EPI_F32, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// AutoencoderKL of the SD family (diffusers Encoder / Decoder: the same ResnetBlock2D without a time embedding, one single-head
+// attention of head dim = channels in the mid block, Downsample2D with the one-sided padding, Upsample2D), on the same arena and
+// the same weight table.  Weights under diffusers' names: "encoder.*", "quant_conv.*", "post_quant_conv.*", "decoder.*".
+
+// diffusers Attention(heads 1, residual_connection, group_norm) of UNetMidBlock2D, in place on x f32 [hw][C]:
+// x += to_out(softmax(q k^T / sqrt(C)) v), q / k / v = linear(GroupNorm(x)).  Head dim C (512) is outside attn.hip's flash
+// kernel (head dim 64), and there is one such layer per VAE pass: two GEMMs around a row softmax.  V is produced transposed
+// (V^T = W_v . xn^T: the weight is the GEMM's A operand) so that P . V is the "A . W^T" the GEMM computes; v's bias moves
+// behind the softmax (rows of P sum to one: P (V + 1 b^T) = P V + b^T) and becomes the bias of that GEMM.
+static int vae_attention(Unet& u, const std::string& pre, float* x, int H, int W, int C, hipStream_t s) {
+    U_RC(u_check_shape(u, H, W, C, "vae attention"));
+    const int hw = H * W;
+    if (hw % 64) return fail(R3G_ERR_INVALID, "vae attention: %d x %d pixels is not a multiple of 64", H, W);
+    const float *gw, *gb;
+    U_RC(u_vec(u, pre + ".group_norm.weight", C, &gw));
+    U_RC(u_vec(u, pre + ".group_norm.bias", C, &gb));
+    ULin q, k, v, o;
+    U_RC(u_lin(u, pre + ".to_q", true, C, C, &q));
+    U_RC(u_lin(u, pre + ".to_k", true, C, C, &k));
+    U_RC(u_lin(u, pre + ".to_v", true, C, C, &v));
+    U_RC(u_lin(u, pre + ".to_out.0", true, C, C, &o));
+    // scores fp32 [hw][hw] + probabilities bf16 [hw][hw] (64 + 32 MiB at 64 x 64 latents) live in the lazily sized side buffer
+    const size_t need = (size_t)hw * hw * 6;
+    if (need > u.skips_bytes) {
+        if (u.skips) { U_TRY(hipStreamSynchronize(s)); (void)hipFree(u.skips); u.skips = nullptr; u.skips_bytes = 0; }
+        U_TRY(hipMalloc((void**)&u.skips, need));
+        u.skips_bytes = need;
+    }
+    float* S = u.skips;
+    uint16_t* P = reinterpret_cast<uint16_t*>(u.skips + (size_t)hw * hw);
+    U_TRY(group_norm_launch(x, hw, C, u.c.groups, gw, gb, u.c.resnet_eps, 0, u.xn, u.gn_partial, s));
+    U_RC(u_gemm(u.xn, C, q, q.b, u.Q, C, hw, EPI_BF16, s));
+    U_RC(u_gemm(u.xn, C, k, k.b, u.K, C, hw, EPI_BF16, s));
+    {
+        ULin xt;                       // "weight" = the normalised activations [hw][C]: V^T [C][hw] = W_v . xn^T
+        xt.w = u.xn; xt.N = hw; xt.K = C;
+        U_RC(u_gemm(v.w, C, xt, nullptr, u.Vt, hw, C, EPI_BF16, s));
+    }
+    {
+        ULin kt;                       // S = Q . K^T
+        kt.w = u.K; kt.N = hw; kt.K = C;
+        U_RC(u_gemm(u.Q, C, kt, nullptr, S, hw, hw, EPI_F32, s));
+    }
+    U_TRY(softmax_rows_launch(S, hw, P, hw, hw, hw, 1.0f / sqrtf((float)C), s));
+    {
+        ULin vt;                       // O = P . V (+ b_v)
+        vt.w = u.Vt; vt.N = C; vt.K = hw;
+        U_RC(u_gemm(P, hw, vt, v.b, u.att, C, hw, EPI_BF16, s));
+    }
+    return u_gemm(u.att, C, o, o.b, x, C, hw, EPI_RESID_F32, s);
+}
+
+// diffusers UNetMidBlock2D of the VAE: resnet, attention, resnet -- in place on x
+static int vae_mid(Unet& u, const std::string& pre, float* x, int H, int W, int C, hipStream_t s) {
+    U_RC(unet_resnet(u, pre + ".resnets.0", x, H, W, C, C, nullptr, x, s));
+    U_RC(vae_attention(u, pre + ".attentions.0", x, H, W, C, s));
+    return unet_resnet(u, pre + ".resnets.1", x, H, W, C, C, nullptr, x, s);
+}
+
+static int vae_levels(const Unet& u, const char* fn) {
+    const r3g_unet_config& c = u.c;
+    if (c.n_levels < 1 || c.n_levels > 4 || c.layers_per_block < 1)
+        return fail(R3G_ERR_STATE, "%s: the configuration has no block structure", fn);
+    if (c.in_channels < 1 || c.in_channels > 32 || c.out_channels < 1 || c.out_channels > 64)
+        return fail(R3G_ERR_INVALID, "%s: latent channels must be in [1, 32], image channels in [1, 64]", fn);
+    return R3G_OK;
+}
+
+// AutoencoderKL.decode: z f32 [h*w][latent] -> post_quant_conv -> Decoder.forward -> image f32 [(8h)(8w)][rup(image channels, 4)]
+// (for n_levels = 4).  config: block_out_channels = the ENCODER's order (128, 256, 512, 512), in_channels = latent channels,
+// out_channels = image channels.
+static int vae_decode(Unet& u, const float* z, int h, int w, float* out, hipStream_t s) {
+    U_RC(vae_levels(u, "r3g_aekl_decode"));
+    const r3g_unet_config& c = u.c;
+    const int n = c.n_levels, L = c.layers_per_block, zc = c.in_channels;
+    const int* ch = c.block_out_channels;
+    const int ctop = ch[n - 1];
+    U_RC(u_check_shape(u, h << (n - 1), w << (n - 1), ch[0], "r3g_aekl_decode"));
+    U_RC(u_check_shape(u, h, w, ctop, "r3g_aekl_decode"));
+    // post_quant_conv (1x1, latent -> latent; K zero-padded to 64 in the operand and in the re-laid weight)
+    ULin pq, ci;
+    U_RC(u_lin(u, "post_quant_conv", true, rup(zc, 4), 64, &pq));
+    U_RC(u_lin(u, "decoder.conv_in", true, ctop, 9 * 64, &ci));
+    const int zp = (int)rup(zc, 4);
+    U_TRY(cast_pad_launch(z, zc, u.xn, 64, h * w, zc, 64, 1.0f, s));
+    U_RC(u_gemm(u.xn, 64, pq, pq.b, u.t1, zp, h * w, EPI_F32, s));
+    U_TRY(cast_pad_launch(u.t1, zp, u.xn, 64, h * w, zc, 64, 1.0f, s));
+    int side = 0;
+    U_RC(u_conv3x3(u, u.xn, h, w, 64, 1, ci, ci.b, u.hb[side], EPI_F32, s));
+    U_RC(vae_mid(u, "decoder.mid_block", u.hb[side], h, w, ctop, s));
+    int hh = h, ww = w, cc = ctop;
+    for (int i = 0; i < n; ++i) {
+        const int cout = ch[n - 1 - i];
+        const std::string pre = "decoder.up_blocks." + std::to_string(i);
+        for (int j = 0; j <= L; ++j) {
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), u.hb[side], hh, ww, cc, cout, nullptr, u.hb[side ^ 1], s));
+            side ^= 1;
+            cc = cout;
+        }
+        if (i < n - 1) {
+            U_RC(unet_upsample(u, pre + ".upsamplers.0", u.hb[side], hh, ww, cc, u.hb[side ^ 1], s));
+            side ^= 1;
+            hh *= 2; ww *= 2;
+        }
+    }
+    const float *gw, *gb;
+    U_RC(u_vec(u, "decoder.conv_norm_out.weight", cc, &gw));
+    U_RC(u_vec(u, "decoder.conv_norm_out.bias", cc, &gb));
+    ULin co;
+    U_RC(u_lin(u, "decoder.conv_out", true, (int)rup(c.out_channels, 4), 9 * cc, &co));
+    U_TRY(group_norm_launch(u.hb[side], hh * ww, cc, c.groups, gw, gb, c.resnet_eps, 1, u.xn, u.gn_partial, s));
+    return u_conv3x3(u, u.xn, hh, ww, cc, 1, co, co.b, out, EPI_F32, s);
+}
+
+// AutoencoderKL.encode up to the moments: image f32 [H*W][image channels] -> Encoder.forward -> quant_conv -> f32 [(H/8)(W/8)][2 latent]
+// (mean | log-variance; the latent distribution's mode is the first half)
+static int vae_encode(Unet& u, const float* img, int H, int W, float* out, hipStream_t s) {
+    U_RC(vae_levels(u, "r3g_aekl_encode"));
+    const r3g_unet_config& c = u.c;
+    const int n = c.n_levels, L = c.layers_per_block, zc2 = 2 * c.in_channels;
+    const int* ch = c.block_out_channels;
+    if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) return fail(R3G_ERR_INVALID, "r3g_aekl_encode: %d x %d is not divisible by %d", H, W, 1 << (n - 1));
+    U_RC(u_check_shape(u, H, W, ch[0], "r3g_aekl_encode"));
+    ULin ci;
+    U_RC(u_lin(u, "encoder.conv_in", true, ch[0], 9 * 64, &ci));
+    U_TRY(cast_pad_launch(img, c.out_channels, u.xn, 64, H * W, c.out_channels, 64, 1.0f, s));
+    int side = 0;
+    U_RC(u_conv3x3(u, u.xn, H, W, 64, 1, ci, ci.b, u.hb[side], EPI_F32, s));
+    int hh = H, ww = W, cc = ch[0];
+    for (int i = 0; i < n; ++i) {
+        const std::string pre = "encoder.down_blocks." + std::to_string(i);
+        for (int j = 0; j < L; ++j) {
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), u.hb[side], hh, ww, cc, ch[i], nullptr, u.hb[side ^ 1], s));
+            side ^= 1;
+            cc = ch[i];
+        }
+        if (i < n - 1) {     // Downsample2D(padding 0): F.pad(x, (0, 1, 0, 1)), conv 3x3 stride 2
+            ULin cv;
+            U_RC(u_lin(u, pre + ".downsamplers.0.conv", true, cc, 9 * cc, &cv));
+            U_TRY(f32_to_bf16_launch(u.hb[side], u.xn, (int64_t)hh * ww * cc, s));
+            U_RC(u_conv3x3(u, u.xn, hh, ww, cc, 2, cv, cv.b, u.hb[side ^ 1], EPI_F32, s, 0));
+            side ^= 1;
+            hh /= 2; ww /= 2;
+        }
+    }
+    U_RC(vae_mid(u, "encoder.mid_block", u.hb[side], hh, ww, cc, s));
+    const float *gw, *gb;
+    U_RC(u_vec(u, "encoder.conv_norm_out.weight", cc, &gw));
+    U_RC(u_vec(u, "encoder.conv_norm_out.bias", cc, &gb));
+    ULin co, qc;
+    const int zp = (int)rup(zc2, 4);
+    U_RC(u_lin(u, "encoder.conv_out", true, zp, 9 * cc, &co));
+    U_RC(u_lin(u, "quant_conv", true, zp, 64, &qc));
+    U_TRY(group_norm_launch(u.hb[side], hh * ww, cc, c.groups, gw, gb, c.resnet_eps, 1, u.xn, u.gn_partial, s));
+    U_RC(u_conv3x3(u, u.xn, hh, ww, cc, 1, co, co.b, u.t1, EPI_F32, s));
+    U_TRY(cast_pad_launch(u.t1, zp, u.xn, 64, hh * ww, zc2, 64, 1.0f, s));
+    return u_gemm(u.xn, 64, qc, qc.b, out, zp, hh * ww, EPI_F32, s);
+}
+
 static void unet_free(Unet* u) {
     if (!u) return;
     if (u->arena) (void)hipFree(u->arena);
@@ -516,6 +684,18 @@ int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int h
     rc = unet_transformer(*u, pre + ".attentions.0", d_out, height, width, channels, d_ctx, tokens, s);
     if (rc) return rc;
     return unet_resnet(*u, pre + ".resnets.1", d_out, height, width, channels, channels, d_temb, d_out, s);
+}
+
+int r3g_aekl_decode(r3g_ctx* ctx, const float* d_latent, int height, int width, float* d_image, void* stream) {
+    NEED_UNET("r3g_aekl_decode");
+    if (!d_latent || !d_image) return fail(R3G_ERR_INVALID, "r3g_aekl_decode: null argument");
+    return vae_decode(*u, d_latent, height, width, d_image, (hipStream_t)stream);
+}
+
+int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, float* d_moments, void* stream) {
+    NEED_UNET("r3g_aekl_encode");
+    if (!d_image || !d_moments) return fail(R3G_ERR_INVALID, "r3g_aekl_encode: null argument");
+    return vae_encode(*u, d_image, height, width, d_moments, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 """Host side of the texture stage's UNet blocks (include/r3g.h "UNet blocks"): diffusers state dict -> device weights in the
-layouts the kernels read, and thin methods over the C ABI.  SURVEY.md 8(f) rank 3, first slice: building blocks only --
-nothing in the stage uses them yet (hy3dgen.texgen keeps reporting where its colours come from).
+layouts the kernels read, and thin methods over the C ABI.  SURVEY.md 8(f) rank 3: the UNet (UnetBlocks) and the SD-family
+VAE (AutoencoderKLBlocks) that upstream's texture pipelines are made of -- nothing in the stage uses them yet (hy3dgen.texgen
+keeps reporting where its colours come from).
 
 State-dict names are diffusers' (`unet/diffusion_pytorch_model.safetensors` of an SD-2.1-class model):
 "down_blocks.0.resnets.0.conv1.weight", "mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight", ...
@@ -153,3 +154,87 @@ class UnetBlocks:
             _l.check(self.L.r3g_unet_mid_block(self.ctx, prefix.encode(), rows.data_ptr(), h, w, c, t.data_ptr(), cx.data_ptr(),
                                                cx.shape[0], out.data_ptr(), self._s()))
         return from_rows(out, h, w)
+
+
+def prepare_aekl_weights(sd, device):
+    """AutoencoderKL state dict -> the layouts r3g_aekl_encode / r3g_aekl_decode read (pure re-layouts and zero padding):
+    3x3 conv [O][I][3][3] -> [O][ky][kx][I] with I zero-padded to a multiple of 64 (conv_in); 1x1 conv -> [O][I], I padded to
+    64 (quant_conv, post_quant_conv); O (and the bias) zero-padded to a multiple of 4 (conv_out: 3 image channels); linear
+    layers of the mid block's attention as they are; matrices bf16, vectors f32"""
+    out = {}
+    for k, t in sd.items():
+        t = t.detach().to(torch.float32)
+        if t.ndim == 4:
+            if t.shape[-1] == 3:
+                t = t.permute(0, 2, 3, 1)
+                if t.shape[-1] % 64:
+                    t = torch.cat([t, torch.zeros(t.shape[:3] + (64 - t.shape[-1] % 64,), dtype=t.dtype)], dim=-1)
+                t = t.reshape(t.shape[0], -1)
+            else:
+                t = t.reshape(t.shape[0], t.shape[1])
+                if t.shape[1] % 64:
+                    t = torch.cat([t, torch.zeros((t.shape[0], 64 - t.shape[1] % 64), dtype=t.dtype)], dim=1)
+        if t.ndim == 2:
+            if t.shape[0] % 4:
+                t = torch.cat([t, torch.zeros((4 - t.shape[0] % 4, t.shape[1]), dtype=t.dtype)], dim=0)
+            out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
+        else:
+            t = t.reshape(-1)
+            if t.numel() % 4:
+                t = torch.cat([t, torch.zeros(4 - t.numel() % 4, dtype=t.dtype)])
+            out[k] = (t.reshape(1, -1).to(device=device).contiguous(), 0)
+    return out
+
+
+class AutoencoderKLBlocks:
+    """diffusers AutoencoderKL (SD family) on the HIP blocks: encode(image) -> moments, decode(latent) -> image"""
+
+    def __init__(self, state_dict, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
+                 image_channels=3, groups=32, max_image_hw=512 * 512, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("r3g.unet needs an MI355X: libr3g has no CPU path")
+        self.device = torch.device("cuda", device)
+        self.ctx = _l.new_context(device)
+        self.L = _l.lib()
+        self.factor = 2 ** (len(block_out_channels) - 1)
+        self.latent_channels, self.image_channels = int(latent_channels), int(image_channels)
+        c = _l.UnetConfig(int(max_image_hw), int(max(block_out_channels)), 8, 64, 1, int(groups), 1e-6, len(block_out_channels),
+                          int(layers_per_block), int(latent_channels), int(image_channels),
+                          (ctypes.c_int32 * 4)(*(list(block_out_channels) + [0] * (4 - len(block_out_channels)))))
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_create(self.ctx, ctypes.byref(c)))
+            self._w = prepare_aekl_weights(state_dict, self.device)
+            for name, (t, code) in self._w.items():
+                _l.check(self.L.r3g_unet_set_tensor(self.ctx, name.encode(), t.data_ptr(), code, t.shape[0], t.shape[1]))
+            torch.cuda.synchronize()
+
+    def _s(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def decode(self, z):
+        """AutoencoderKL.decode(z).sample: z NCHW [1, latent, h, w] -> NCHW [1, image channels, f h, f w]"""
+        _, zc, h, w = z.shape
+        if zc != self.latent_channels:
+            raise ValueError("latent has %d channels, the model %d" % (zc, self.latent_channels))
+        rows = to_rows(z.to(self.device))
+        f = self.factor
+        out = torch.empty((f * h * f * w, (self.image_channels + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_aekl_decode(self.ctx, rows.data_ptr(), h, w, out.data_ptr(), self._s()))
+        return from_rows(out[:, :self.image_channels], f * h, f * w)
+
+    def encode(self, x):
+        """parameters of AutoencoderKL.encode(x).latent_dist: x NCHW [1, image channels, H, W] -> NCHW [1, 2 latent, H/f, W/f]
+        (mean | log-variance); latent_dist.mode() is the first half"""
+        _, c, h, w = x.shape
+        if c != self.image_channels:
+            raise ValueError("image has %d channels, the model %d" % (c, self.image_channels))
+        f = self.factor
+        if h % f or w % f:
+            raise ValueError("image size must be divisible by %d" % f)
+        rows = to_rows(x.to(self.device))
+        zc2 = 2 * self.latent_channels
+        out = torch.empty(((h // f) * (w // f), (zc2 + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_aekl_encode(self.ctx, rows.data_ptr(), h, w, out.data_ptr(), self._s()))
+        return from_rows(out[:, :zc2], h // f, w // f)

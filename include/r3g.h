@@ -278,6 +278,23 @@ int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width,
 int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,
                        const float* d_temb, const uint16_t* d_ctx, int tokens, float* d_out, void* stream);
 
+/* ---- the SD-family VAE (diffusers AutoencoderKL) on the same blocks ------------------------------
+ * Replaces, inside upstream's texture pipelines (behind reference src/2d_to_3d_models/run.py:97), `vae.encode(image)` /
+ * `vae.decode(latents)` of the delight and multiview diffusion models.  The context is one created by r3g_unet_create with
+ * block_out_channels = the ENCODER's order (128, 256, 512, 512), layers_per_block 2, in_channels = latent channels (4),
+ * out_channels = image channels (3), groups 32, resnet_eps 1e-6; weights registered with r3g_unet_set_tensor under diffusers'
+ * names ("encoder.down_blocks.0.resnets.0.conv1.weight", "decoder.mid_block.attentions.0.to_q.weight", "quant_conv.weight",
+ * "post_quant_conv.weight", ...), 3x3 convolutions re-laid as for the UNet, conv_in's input channels and the 1x1 convolutions'
+ * K zero-padded to 64, conv_out / quant_conv / post_quant_conv rows zero-padded to a multiple of 4 (python: r3g.unet).
+ * The mid block's single-head attention (head dim = channels) is two GEMMs around a row softmax; height*width of the
+ * latent grid must be a multiple of 64. */
+/* AutoencoderKL.decode(z).sample: d_latent f32 [height*width][latent channels] (already divided by the scaling factor) ->
+ * d_image f32 [(8 height)(8 width)][4] (channels 0..2 = RGB in [-1, 1] nominally, channel 3 = 0) */
+int r3g_aekl_decode(r3g_ctx* ctx, const float* d_latent, int height, int width, float* d_image, void* stream);
+/* AutoencoderKL.encode(x).latent_dist parameters: d_image f32 [height*width][image channels] -> d_moments f32
+ * [(height/8)(width/8)][2 latent channels] = (mean | log-variance); the distribution's mode is the mean */
+int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, float* d_moments, void* stream);
+
 /* ---- single kernels, for parity tests through the ABI ------------------------------------------ */
 /* C = epilogue(A[m][k] . W[n][k]^T + bias); epilogue: 0 bf16, 1 bf16 gelu(tanh), 2 bf16 gelu(erf),
  * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
