@@ -206,6 +206,32 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+// ---- the sampling loop of an InstructPix2Pix-class pipeline (upstream's delighting model), around r3g_unet_forward --------
+// UNet input rows: out[p] = (latent[p] / sqrt(sigma^2 + 1) | image_latent[p])   (scheduler.scale_model_input + torch.cat(dim=1))
+__global__ __launch_bounds__(256) void pix2pix_input_kernel(const float* __restrict__ lat, const float* __restrict__ img, int zc,
+                                                            int64_t n, float inv, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over pixels x 2 zc
+    if (i >= n * 2 * zc) return;
+    const int64_t p = i / (2 * zc);
+    const int c = (int)(i - p * 2 * zc);
+    out[i] = c < zc ? lat[p * zc + c] * inv : img[p * zc + (c - zc)];
+}
+
+// diffusers EulerAncestralDiscreteScheduler.step, in place on the sample: x0 = x - sigma eps (epsilon) or
+// v (-sigma / sqrt(sigma^2 + 1)) + x / (sigma^2 + 1) (v_prediction); derivative = (x - x0) / sigma;
+// x <- x + derivative (sigma_down - sigma) + noise sigma_up
+__global__ __launch_bounds__(256) void euler_ancestral_step_kernel(float* __restrict__ x, const float* __restrict__ m,
+                                                                   const float* __restrict__ noise, int64_t n, float sigma, float dt,
+                                                                   float sigma_up, int vpred) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xi = x[i], mi = m[i];
+    const float s2 = sigma * sigma + 1.0f;
+    const float x0 = vpred ? mi * (-sigma / sqrtf(s2)) + xi / s2 : xi - sigma * mi;
+    const float d = (xi - x0) / sigma;
+    x[i] = xi + d * dt + noise[i] * sigma_up;
+}
+
 // diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): out[dim] = [cos(t f_k) | sin(t f_k)],
 // f_k = exp(-ln(10000) k / (dim/2))
 __global__ void unet_timestep_kernel(float t, int dim, float* __restrict__ out) {
@@ -286,6 +312,27 @@ hipError_t softmax_rows_launch(const float* S, int64_t lds, uint16_t* P, int64_t
     if (rows < 1 || n < 4 || n % 4 || (lds & 3) || (ldp & 3)) return hipErrorInvalidValue;
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, P, ldp, n, scale * 1.4426950408889634f);
+    return hipGetLastError();
+}
+
+hipError_t pix2pix_input_launch(const float* lat, const float* img, int zc, int64_t pixels, float sigma, float* out, hipStream_t s) {
+    if (zc < 1 || pixels < 1) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);
+    hipLaunchKernelGGL(pix2pix_input_kernel, dim3(blocks_for(pixels * 2 * zc, 256)), dim3(256), 0, s, lat, img, zc, pixels, inv, out);
+    return hipGetLastError();
+}
+
+hipError_t euler_ancestral_step_launch(float* x, const float* model_out, const float* noise, int64_t n, float sigma_from,
+                                       float sigma_to, int vpred, hipStream_t s) {
+    if (n < 1 || !(sigma_from > 0.0f) || sigma_to < 0.0f || sigma_to > sigma_from) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    // fp32, in diffusers' order of operations
+    const float f2 = sigma_from * sigma_from, t2 = sigma_to * sigma_to;
+    const float sigma_up = sqrtf(t2 * (f2 - t2) / f2);
+    const float sigma_down = sqrtf(t2 - sigma_up * sigma_up);
+    hipLaunchKernelGGL(euler_ancestral_step_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, model_out, noise, n, sigma_from,
+                       sigma_down - sigma_from, sigma_up, vpred);
     return hipGetLastError();
 }
 

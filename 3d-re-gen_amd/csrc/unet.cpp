@@ -698,4 +698,24 @@ int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, f
     return vae_encode(*u, d_image, height, width, d_moments, (hipStream_t)stream);
 }
 
+int r3g_sched_pix2pix_input(const float* d_latent, const float* d_image_latent, int channels, int64_t pixels, float sigma,
+                            float* d_out, void* stream) {
+    if (!d_latent || !d_image_latent || !d_out || channels < 1 || pixels < 1 || !(sigma >= 0.0f))
+        return fail(R3G_ERR_INVALID, "r3g_sched_pix2pix_input: bad argument");
+    hipError_t e = pix2pix_input_launch(d_latent, d_image_latent, channels, pixels, sigma, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "pix2pix_input_launch");
+    return R3G_OK;
+}
+
+int r3g_sched_euler_ancestral_step(float* d_sample, const float* d_model_out, const float* d_noise, int64_t n, float sigma_from,
+                                   float sigma_to, int prediction_type, void* stream) {
+    if (!d_sample || !d_model_out || !d_noise || n < 1 || (prediction_type != 0 && prediction_type != 1))
+        return fail(R3G_ERR_INVALID, "r3g_sched_euler_ancestral_step: bad argument");
+    if (!(sigma_from > 0.0f) || sigma_to < 0.0f || sigma_to > sigma_from)
+        return fail(R3G_ERR_INVALID, "r3g_sched_euler_ancestral_step: sigmas must satisfy 0 <= sigma_to <= sigma_from, sigma_from > 0");
+    hipError_t e = euler_ancestral_step_launch(d_sample, d_model_out, d_noise, n, sigma_from, sigma_to, prediction_type, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "euler_ancestral_step_launch");
+    return R3G_OK;
+}
+
 }  // extern "C"

@@ -6,7 +6,9 @@ image-to-image diffusion model -> UV-unwrap the mesh (xatlas) -> render normal /
 native `custom_rasterizer` -> generate the six views with a multiview diffusion UNet -> back-project and blend them into a
 UV texture -> inpaint what no view saw (`mesh_processor.meshVerticeInpaint` + cv2) -> textured mesh.
 
-What exists here (partial): everything EXCEPT the two diffusion models.  The native pieces run as HIP
+What exists here (partial): everything EXCEPT the multiview diffusion model.  The delighting model
+(`delight_model=`: hy3dgen.texgen.utils.dehighlight_utils.Light_Shadow_Remover -- SD-2.x UNet, SD VAE and Euler-ancestral loop on
+the HIP blocks) runs when the caller has its checkpoint; without one the input image is used as it is.  The native pieces run as HIP
 kernels behind the C ABI (r3g.texops: rasterise, interpolate, view weights, fixed-point baking, vertex-propagation
 inpainting); the unwrap is r3g.uvatlas.chart_atlas (axis-projected height-field charts at uniform texel density; the per-face
 atlas of rounds 1-2 remains as `atlas="face"`).  The views that get baked are
@@ -43,11 +45,14 @@ class Hunyuan3DPaintPipeline:
     implemented = True
 
     def __init__(self, texture_size=None, render_size=None, multiview_model=None, views=None, cos_threshold=0.1,
-                 depth_edge=0.02, power=4.0, dilate_iters=8, device=None, atlas=None):
+                 depth_edge=0.02, power=4.0, dilate_iters=8, device=None, atlas=None, delight_model=None):
         # upstream: texture_size 2048, render_size 2048; R3G_TEX_SIZE / R3G_TEX_RENDER override the defaults (tests)
         self.texture_size = int(texture_size or os.environ.get("R3G_TEX_SIZE", 2048))
         self.render_size = int(render_size or os.environ.get("R3G_TEX_RENDER", 1024))
         self.multiview_model = multiview_model
+        # upstream: self.models['delight_model'] = Light_Shadow_Remover(config), applied to the image first thing in __call__;
+        # here an instance of hy3dgen.texgen.utils.dehighlight_utils.Light_Shadow_Remover (HIP UNet + VAE) when the caller has one
+        self.delight_model = delight_model
         self.views = list(views) if views is not None else list(DEFAULT_VIEWS)
         self.cos_threshold, self.depth_edge, self.power = float(cos_threshold), float(depth_edge), float(power)
         self.dilate_iters = int(dilate_iters)
@@ -59,21 +64,32 @@ class Hunyuan3DPaintPipeline:
 
     @property
     def source(self):
+        pre = "delighted input; " if self.delight_model is not None else ""
         if self.multiview_model is not None:
-            return "multiview model supplied by the caller, %d views baked" % len(self.views)
-        return "input view only (no multiview diffusion model on this path); unseen texels filled by propagation over the mesh"
+            return pre + "multiview model supplied by the caller, %d views baked" % len(self.views)
+        return pre + "input view only (no multiview diffusion model on this path); unseen texels filled by propagation over the mesh"
 
     @classmethod
     def from_pretrained(cls, model_path=None, subfolder=None, **kwargs):
         """upstream loads the delight and multiview diffusion checkpoints here; this path has neither (see module doc)"""
         allowed = ("texture_size", "render_size", "multiview_model", "views", "cos_threshold", "depth_edge", "power",
-                   "dilate_iters", "device", "atlas")
+                   "dilate_iters", "device", "atlas", "delight_model")
         return cls(**{k: v for k, v in kwargs.items() if k in allowed})
 
     # -- helpers -----------------------------------------------------------------------------------------------------
     def _device(self):
         import torch
         return torch.device(self.device or ("cuda:%d" % torch.cuda.current_device()))
+
+    def _delight(self, image):
+        """upstream: image_prompt = self.models['delight_model'](image_prompt).  The delighted picture comes back as RGB over
+        white at the model's size; the alpha it is registered by stays the input's."""
+        from PIL import Image
+        out = self.delight_model(image)
+        if out.mode != "RGBA" and image.mode == "RGBA":
+            out = out.convert("RGB")
+            out.putalpha(image.getchannel("A").resize(out.size, Image.BILINEAR))
+        return out
 
     def _front_image(self, image):
         """RGBA PIL image -> (rgb float32 [R, R, 3] in [0, 1], alpha float32 [R, R], alpha bbox in [0, 1] image coordinates)"""
@@ -97,6 +113,8 @@ class Hunyuan3DPaintPipeline:
             raise ValueError("Hunyuan3DPaintPipeline needs the object's image")
         if mesh.is_empty:
             return mesh
+        if self.delight_model is not None:
+            image = self._delight(image)
         dev = self._device()
         v = np.ascontiguousarray(mesh.vertices, np.float32)
         f = np.ascontiguousarray(mesh.faces, np.int32)

@@ -1,0 +1,136 @@
+"""hy3dgen.texgen.utils.dehighlight_utils -- MI355X mirror of upstream's delighting step (`Light_Shadow_Remover`), the first
+thing `Hunyuan3DPaintPipeline.__call__` does with the object's image (behind reference src/2d_to_3d_models/run.py:97).
+
+[UPSTREAM-RECALLED] upstream builds a diffusers StableDiffusionInstructPix2PixPipeline from `config.light_remover_ckpt_path`,
+replaces its scheduler by EulerAncestralDiscreteScheduler.from_config, and its __call__ is: resize to 512 x 512; for RGBA erode
+the alpha by a 3 x 3 kernel and paint what falls outside white; run the pipeline (prompt "", generator torch.manual_seed(42),
+50 steps, image_guidance_scale 1.5, guidance_scale 1.0); match the result's per-channel mean / standard deviation over the
+object to the input's (`recorrect_rgb`, kept only if it lowers the mean squared difference to the input); composite over white.
+The class and method names, the call signature and those constants are upstream's; neither hy3dgen nor diffusers is in the
+container, so none of this is pinned against them.
+
+Here the diffusion model itself runs on the HIP blocks (r3g.delight.InstructPix2Pix: UNet + SD VAE + Euler-ancestral loop);
+the image bookkeeping around it (a 512 x 512 erode, four means and standard deviations) is host numpy.  The prompt embedding
+of "" is an input (one constant tensor; the CLIP text encoder is not on this path)."""
+import json
+import os
+
+import numpy as np
+
+
+def erode3(alpha):
+    """cv2.erode(alpha, np.ones((3, 3), np.uint8), iterations=1): minimum over the 3 x 3 neighbourhood; cv2's default border
+    for erosion does not lower the result (the border counts as +infinity)"""
+    a = np.asarray(alpha)
+    p = np.pad(a, 1, mode="constant", constant_values=np.iinfo(a.dtype).max if a.dtype.kind in "ui" else np.inf)
+    out = a.copy()
+    for dy in range(3):
+        for dx in range(3):
+            out = np.minimum(out, p[dy:dy + a.shape[0], dx:dx + a.shape[1]])
+    return out
+
+
+def recorrect_rgb(src, target, alpha, scale=0.95):
+    """upstream `recorrect_rgb`: per channel (src - scale mean_src) (std_tgt / std_src) + scale mean_tgt over alpha > 0.5,
+    clamped to [0, 1]; kept only if it is closer (mean squared difference over the whole image) to the target than src is.
+    src, target float [H, W, 3] in [0, 1], alpha float [H, W, 1] -> float [H, W, 4] (rgb | alpha)"""
+    src, target, alpha = np.asarray(src, np.float64), np.asarray(target, np.float64), np.asarray(alpha, np.float64)
+    m = alpha[..., 0] > 0.5
+    out = np.zeros_like(src)
+    for c in range(3):
+        s, t = src[..., c][m], target[..., c][m]
+        # torch.std is the unbiased estimator
+        s_mean, s_std = s.mean(), s.std(ddof=1)
+        t_mean, t_std = t.mean(), t.std(ddof=1)
+        out[..., c] = np.clip((src[..., c] - scale * s_mean) * (t_std / s_std) + scale * t_mean, 0.0, 1.0)
+    keep_src = np.mean((src - target) ** 2) < np.mean((out - target) ** 2)
+    return np.concatenate([src if keep_src else out, alpha], axis=-1)
+
+
+class Light_Shadow_Remover:
+    cfg_image = 1.5      # image_guidance_scale (inert while cfg_text <= 1: diffusers then runs no guidance at all)
+    cfg_text = 1.0       # guidance_scale
+    size = 512
+    steps = 50
+    seed = 42
+
+    def __init__(self, config=None, model=None, prompt_embeds=None):
+        """model: an r3g.delight.InstructPix2Pix; prompt_embeds: the text encoder's output for the prompt "" [1, tokens, dim].
+        With a config that carries `light_remover_ckpt_path` (upstream's attribute) both are read from that diffusers
+        checkpoint directory (from_pretrained)."""
+        if model is None:
+            path = getattr(config, "light_remover_ckpt_path", None) if config is not None else None
+            if not path:
+                raise ValueError("Light_Shadow_Remover needs a model or config.light_remover_ckpt_path")
+            model, prompt_embeds = self.load(path, device=getattr(config, "device", 0))
+        if prompt_embeds is None:
+            raise ValueError("Light_Shadow_Remover needs the text embedding of the empty prompt")
+        self.model = model
+        self.prompt_embeds = prompt_embeds
+
+    @staticmethod
+    def load(path, device=0):
+        """a diffusers InstructPix2Pix checkpoint directory: unet/ and vae/ (config.json + diffusion_pytorch_model.safetensors)
+        and `prompt_embeds_empty.safetensors` (key "prompt_embeds": the text encoder's last hidden state for the prompt "",
+        computed once with the checkpoint's own tokenizer / text_encoder -- INTEGRATION.md)"""
+        from safetensors.torch import load_file
+        from r3g.delight import InstructPix2Pix
+
+        def cfg(sub):
+            with open(os.path.join(path, sub, "config.json")) as f:
+                return json.load(f)
+        uc, vc = cfg("unet"), cfg("vae")
+        ch = tuple(uc["block_out_channels"])
+        heads = uc.get("attention_head_dim", 8)
+        heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(ch)
+        if any(c // h_ != 64 for c, h_ in zip(ch, heads)):
+            raise ValueError("this path runs head dim 64 (the SD 2.x layout: attention_head_dim = heads per block)")
+        if not uc.get("use_linear_projection", False):
+            raise ValueError("this path needs use_linear_projection (SD 2.x)")
+        sched_cfg = {}
+        sp = os.path.join(path, "scheduler", "scheduler_config.json")
+        if os.path.exists(sp):
+            with open(sp) as f:
+                sched_cfg = json.load(f)
+        prompt = load_file(os.path.join(path, "prompt_embeds_empty.safetensors"))["prompt_embeds"]
+        unet_config = dict(block_out_channels=ch, layers_per_block=uc.get("layers_per_block", 2),
+                           cross_attention_dim=uc["cross_attention_dim"], ctx_tokens=int(prompt.shape[-2]),
+                           temb_dim=4 * ch[0], groups=uc.get("norm_num_groups", 32))
+        vae_config = dict(block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
+                          latent_channels=vc.get("latent_channels", 4), image_channels=vc.get("in_channels", 3),
+                          groups=vc.get("norm_num_groups", 32))
+        model = InstructPix2Pix(load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")),
+                                load_file(os.path.join(path, "vae", "diffusion_pytorch_model.safetensors")), unet_config,
+                                vae_config, image_size=Light_Shadow_Remover.size,
+                                scaling_factor=vc.get("scaling_factor", 0.18215),
+                                prediction_type=sched_cfg.get("prediction_type", "epsilon"), device=device)
+        return model, prompt.reshape(1, prompt.shape[-2], prompt.shape[-1])
+
+    def prepare(self, image):
+        """PIL image -> (rgb uint8 [S, S, 3] fed to the model, rgb_target float [S, S, 3], alpha float [S, S, 1])"""
+        image = image.resize((self.size, self.size))
+        arr = np.array(image)
+        if image.mode == "RGBA":
+            alpha = erode3(arr[:, :, 3])
+            arr[alpha == 0, :3] = 255
+            arr[:, :, 3] = alpha
+            t = arr / 255.0
+            return np.ascontiguousarray(arr[:, :, :3]), t[:, :, :3], t[:, :, 3:]
+        arr = np.array(image.convert("RGB"))
+        t = arr / 255.0
+        return arr, t, np.ones_like(t[:, :, :1])
+
+    def finish(self, out_rgb_u8, rgb_target, alpha):
+        """the model's uint8 output -> colour-corrected, composited over white -> PIL RGB image"""
+        from PIL import Image
+        img = recorrect_rgb(out_rgb_u8 / 255.0, rgb_target, alpha)
+        img = img[:, :, :3] * img[:, :, 3:] + (1.0 - img[:, :, 3:])
+        return Image.fromarray((img * 255).astype(np.uint8))
+
+    def __call__(self, image):
+        import torch
+        rgb, target, alpha = self.prepare(image)
+        x = torch.from_numpy(rgb.astype(np.float32) / 255.0).permute(2, 0, 1)[None] * 2.0 - 1.0       # diffusers VaeImageProcessor
+        out = self.model(x, self.prompt_embeds, num_inference_steps=self.steps, generator=torch.Generator().manual_seed(self.seed))
+        out = (out[0] / 2 + 0.5).clamp(0, 1).permute(1, 2, 0).float().cpu().numpy()
+        return self.finish((out * 255).round().astype(np.uint8), target, alpha)

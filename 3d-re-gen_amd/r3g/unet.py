@@ -146,6 +146,16 @@ class UnetBlocks:
                                              cx.shape[0], out.data_ptr(), self._s()))
         return from_rows(out, h, w)
 
+    def forward_rows(self, rows, h, w, timestep, ctx_rows, out=None):
+        """the same on rows already in HBM (a sampling loop keeps them there): rows f32 [h*w][in_channels], ctx_rows bf16
+        [tokens][ctx_dim] -> f32 [h*w][out_channels]"""
+        if out is None:
+            out = torch.empty((h * w, self.out_channels), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_forward(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), ctx_rows.data_ptr(),
+                                             ctx_rows.shape[0], out.data_ptr(), self._s()))
+        return out
+
     def mid_block(self, prefix, x, temb, ctx):
         _, c, h, w = x.shape
         rows, t, cx = self._in(x, temb, ctx)
@@ -222,6 +232,14 @@ class AutoencoderKLBlocks:
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_aekl_decode(self.ctx, rows.data_ptr(), h, w, out.data_ptr(), self._s()))
         return from_rows(out[:, :self.image_channels], f * h, f * w)
+
+    def decode_rows(self, rows, h, w):
+        """latent rows f32 [h*w][latent] -> image rows f32 [(f h)(f w)][rup(image channels, 4)]"""
+        f = self.factor
+        out = torch.empty((f * h * f * w, (self.image_channels + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_aekl_decode(self.ctx, rows.data_ptr(), h, w, out.data_ptr(), self._s()))
+        return out
 
     def encode(self, x):
         """parameters of AutoencoderKL.encode(x).latent_dist: x NCHW [1, image channels, H, W] -> NCHW [1, 2 latent, H/f, W/f]

@@ -295,6 +295,19 @@ int r3g_aekl_decode(r3g_ctx* ctx, const float* d_latent, int height, int width, 
  * [(height/8)(width/8)][2 latent channels] = (mean | log-variance); the distribution's mode is the mean */
 int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, float* d_moments, void* stream);
 
+/* ---- sampling loop of upstream's delighting model (StableDiffusionInstructPix2PixPipeline with an
+ * EulerAncestralDiscreteScheduler, [UPSTREAM-RECALLED] hy3dgen/texgen/utils/dehighlight_utils.py) around r3g_unet_forward:
+ * the two elementwise steps diffusers runs between UNet evaluations.  Stateless (no context). */
+/* d_out f32 [pixels][2 channels] = (d_latent[p] / sqrt(sigma^2 + 1) | d_image_latent[p]):
+ * scheduler.scale_model_input(latents, t) and torch.cat([latents, image_latents], dim=1) on rows */
+int r3g_sched_pix2pix_input(const float* d_latent, const float* d_image_latent, int channels, int64_t pixels, float sigma,
+                            float* d_out, void* stream);
+/* EulerAncestralDiscreteScheduler.step in place on d_sample f32 [n]: prediction_type 0 epsilon | 1 v_prediction;
+ * sigma_up^2 = sigma_to^2 (sigma_from^2 - sigma_to^2) / sigma_from^2, sigma_down^2 = sigma_to^2 - sigma_up^2,
+ * sample += (sample - x0) / sigma_from * (sigma_down - sigma_from) + d_noise * sigma_up */
+int r3g_sched_euler_ancestral_step(float* d_sample, const float* d_model_out, const float* d_noise, int64_t n, float sigma_from,
+                                   float sigma_to, int prediction_type, void* stream);
+
 /* ---- single kernels, for parity tests through the ABI ------------------------------------------ */
 /* C = epilogue(A[m][k] . W[n][k]^T + bias); epilogue: 0 bf16, 1 bf16 gelu(tanh), 2 bf16 gelu(erf),
  * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
