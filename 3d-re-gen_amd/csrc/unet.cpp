@@ -55,7 +55,19 @@ struct Unet {
     float *catbuf = nullptr, *hb[2] = {nullptr, nullptr}, *emb = nullptr;
     float* skips = nullptr;
     size_t skips_bytes = 0;
+    // several samples per call (the views of the multiview UNet): rows are [nb][H*W][C]; per-sample small vectors
+    float *vecn = nullptr;                 // [kMaxViews][max_channels]: time_emb_proj(silu(emb_n)) of the resnet at hand
+    float *embn = nullptr;                 // [kMaxViews][temb_dim]: time embedding + class embedding of every sample
+    float *gate = nullptr;                 // [2][max_channels]: constant vectors mva_scale / ref_scale (GEMM epilogue gates)
+    // 2.5D transformer blocks ([UPSTREAM-RECALLED] hunyuanpaint/unet/modules.py): what the reference pass writes per
+    // transformer ("condition_embed_dict"), keyed by the transformer's prefix
+    struct Cond { uint16_t* p = nullptr; int64_t rows = 0, cols = 0; size_t cap = 0; };
+    std::unordered_map<std::string, Cond> cond;
+    int nb = 1;                            // samples in the running forward
+    int mv_flags = 0;                      // 1: write the condition store | 2: read it (reference attention)
+    float mva_scale = 1.0f, ref_scale = 1.0f;
 };
+constexpr int kMaxViews = 16;
 
 #define U_TRY(expr)                                            \
     do {                                                       \
@@ -114,8 +126,8 @@ static int u_gemm(const uint16_t* A, int64_t lda, const ULin& l, const float* bi
     return R3G_OK;
 }
 
-static int u_check_shape(const Unet& u, int H, int W, int C, const char* what) {
-    if (H < 1 || W < 1 || (int64_t)H * W > u.c.max_hw || C > u.c.max_channels || C % 64 || C % u.c.groups)
+static int u_check_shape(const Unet& u, int H, int W, int C, const char* what, int nb = 1) {
+    if (H < 1 || W < 1 || nb < 1 || nb > kMaxViews || (int64_t)nb * H * W > u.c.max_hw || C > u.c.max_channels || C % 64 || C % u.c.groups)
         return fail(R3G_ERR_INVALID, "%s: %d x %d x %d does not fit the unet arena (max_hw %d, max_channels %d; C %% 64 == 0)", what,
                     H, W, C, u.c.max_hw, u.c.max_channels);
     return R3G_OK;
@@ -123,20 +135,31 @@ static int u_check_shape(const Unet& u, int H, int W, int C, const char* what) {
 
 // conv 3x3 (pad 1) of bf16 rows src [H*W][Cin] -> epilogue(dst [Ho*Wo][Cout])
 // pad 1: zero padding 1 all round; pad 0: F.pad(x, (0, 1, 0, 1)) (the VAE encoder's stride-2 Downsample2D)
+// nb samples stacked as rows: the im2col runs per sample (a 3x3 window must not reach into the neighbour), the GEMM over all
 static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int stride, const ULin& l, const float* bias, void* dst,
-                     int epi, hipStream_t s, int pad = 1) {
+                     int epi, hipStream_t s, int pad = 1, int nb = 1) {
     const int Ho = (H + pad - 2) / stride + 1, Wo = (W + pad - 2) / stride + 1;
-    U_TRY(im2col3x3_launch(src, H, W, Cin, stride, pad, u.col, s));
-    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, Ho * Wo, epi, s);
+    for (int n = 0; n < nb; ++n)
+        U_TRY(im2col3x3_launch(src + (int64_t)n * H * W * Cin, H, W, Cin, stride, pad, u.col + (int64_t)n * Ho * Wo * 9 * Cin, s));
+    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, nb * Ho * Wo, epi, s);
+}
+
+// GroupNorm (+ SiLU) per sample of f32 rows [nb][hw][C] -> bf16
+static int u_group_norm(Unet& u, const float* x, int hw, int C, const float* g, const float* b, float eps, int silu, uint16_t* y,
+                        hipStream_t s, int nb = 1) {
+    for (int n = 0; n < nb; ++n)
+        U_TRY(group_norm_launch(x + (int64_t)n * hw * C, hw, C, u.c.groups, g, b, eps, silu, y + (int64_t)n * hw * C, u.gn_partial, s));
+    return R3G_OK;
 }
 
 // diffusers ResnetBlock2D.forward: out = shortcut(x) + conv2(silu(norm2(conv1(silu(norm1(x))) + time_emb_proj(silu(temb)))))
-// (temb == nullptr: the VAE's resnets, which have no time_emb_proj)
+// (temb == nullptr: the VAE's resnets, which have no time_emb_proj).  nb samples as rows [nb][H*W][C]; temb_stride != 0: every
+// sample has its own embedding (temb + n temb_stride), added after conv1 as a row vector; otherwise it rides in conv1's bias.
 static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, int W, int Cin, int Cout, const float* temb,
-                       float* out, hipStream_t s) {
-    U_RC(u_check_shape(u, H, W, Cin, "r3g_unet_resnet"));
-    U_RC(u_check_shape(u, H, W, Cout, "r3g_unet_resnet"));
-    const int hw = H * W, G = u.c.groups;
+                       float* out, hipStream_t s, int nb = 1, int64_t temb_stride = 0) {
+    U_RC(u_check_shape(u, H, W, Cin, "r3g_unet_resnet", nb));
+    U_RC(u_check_shape(u, H, W, Cout, "r3g_unet_resnet", nb));
+    const int hw = H * W, rows = nb * hw;
     const float *g1, *b1, *g2, *b2;
     U_RC(u_vec(u, pre + ".norm1.weight", Cin, &g1));
     U_RC(u_vec(u, pre + ".norm1.bias", Cin, &b1));
@@ -147,28 +170,38 @@ static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, i
     U_RC(u_lin(u, pre + ".conv2", true, Cout, 9 * Cout, &c2));
     // per-channel constant of conv1's epilogue: conv1.bias + time_emb_proj(silu(temb))
     const float* cb = c1.b;
+    const bool per_sample = temb && nb > 1 && temb_stride != 0;
     if (temb) {
         U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
-        float* tb = u.vec;
-        float* sum = u.vec + u.c.max_channels;
-        U_TRY(gemv_launch(temb, 1, u.c.temb_dim, tp.w, tp.K, tp.b, tb, Cout, 1, 0, s));
-        U_TRY(vec_add_launch(c1.b, tb, sum, Cout, s));
-        cb = sum;
+        if (per_sample) {
+            for (int n = 0; n < nb; ++n)
+                U_TRY(gemv_launch(temb + n * temb_stride, 1, u.c.temb_dim, tp.w, tp.K, tp.b, u.vecn + (int64_t)n * u.c.max_channels,
+                                  Cout, 1, 0, s));
+        } else {
+            float* tb = u.vec;
+            float* sum = u.vec + u.c.max_channels;
+            U_TRY(gemv_launch(temb, 1, u.c.temb_dim, tp.w, tp.K, tp.b, tb, Cout, 1, 0, s));
+            U_TRY(vec_add_launch(c1.b, tb, sum, Cout, s));
+            cb = sum;
+        }
     }
-    U_TRY(group_norm_launch(x, hw, Cin, G, g1, b1, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
-    U_RC(u_conv3x3(u, u.xn, H, W, Cin, 1, c1, cb, u.t1, EPI_F32, s));
-    U_TRY(group_norm_launch(u.t1, hw, Cout, G, g2, b2, u.c.resnet_eps, 1, u.xn, u.gn_partial, s));
+    U_RC(u_group_norm(u, x, hw, Cin, g1, b1, u.c.resnet_eps, 1, u.xn, s, nb));
+    U_RC(u_conv3x3(u, u.xn, H, W, Cin, 1, c1, cb, u.t1, EPI_F32, s, 1, nb));
+    if (per_sample)
+        for (int n = 0; n < nb; ++n)
+            U_TRY(add_rows_launch(u.t1 + (int64_t)n * hw * Cout, Cout, u.vecn + (int64_t)n * u.c.max_channels, 0, hw, Cout, s));
+    U_RC(u_group_norm(u, u.t1, hw, Cout, g2, b2, u.c.resnet_eps, 1, u.xn, s, nb));
     // the residual: x itself, or conv_shortcut (1x1) of x, lands in `out` first; conv2's epilogue adds onto it
     if (Cin != Cout || u.w.count(pre + ".conv_shortcut.weight")) {
         ULin sc;
         U_RC(u_lin(u, pre + ".conv_shortcut", true, Cout, Cin, &sc));
         uint16_t* xb = u.ff;       // bf16 copy of x (free here)
-        U_TRY(f32_to_bf16_launch(x, xb, (int64_t)hw * Cin, s));
-        U_RC(u_gemm(xb, Cin, sc, sc.b, out, Cout, hw, EPI_F32, s));
+        U_TRY(f32_to_bf16_launch(x, xb, (int64_t)rows * Cin, s));
+        U_RC(u_gemm(xb, Cin, sc, sc.b, out, Cout, rows, EPI_F32, s));
     } else if (out != x) {
-        U_TRY(hipMemcpyAsync(out, x, (size_t)hw * Cout * 4, hipMemcpyDeviceToDevice, s));
+        U_TRY(hipMemcpyAsync(out, x, (size_t)rows * Cout * 4, hipMemcpyDeviceToDevice, s));
     }
-    return u_conv3x3(u, u.xn, H, W, Cout, 1, c2, c2.b, out, EPI_RESID_F32, s);
+    return u_conv3x3(u, u.xn, H, W, Cout, 1, c2, c2.b, out, EPI_RESID_F32, s, 1, nb);
 }
 
 static int u_layernorm(const float* x, uint16_t* y, int rows, int C, const float* w, const float* b, float eps, hipStream_t s) {
@@ -180,11 +213,12 @@ static int u_layernorm(const float* x, uint16_t* y, int rows, int C, const float
     return R3G_OK;
 }
 
+// B independent sequences of Lq queries (Q [B][H][Lq_pad][64]) over Lk keys each; O rows [B][Lq][C]
 static int u_attention(Unet& u, int heads, int Lq, int Lq_pad, int Lk, int Lk_pad, const uint16_t* K, const uint16_t* Vt, int C,
-                       hipStream_t s) {
+                       hipStream_t s, int B = 1) {
     AttnArgs p{};
-    p.Q = u.Q; p.K = K; p.Vt = Vt; p.O = u.att; p.ldo = C; p.strideO = 0;
-    p.B = 1; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
+    p.Q = u.Q; p.K = K; p.Vt = Vt; p.O = u.att; p.ldo = C; p.strideO = (int64_t)Lq * C;
+    p.B = B; p.H = heads; p.Lq = Lq; p.Lq_pad = Lq_pad; p.Lk = Lk; p.Lk_pad = Lk_pad;
     p.scale = 0.125f;
     p.q_prescaled = attn_q_scale(0.125f) != 1.0f;
     hipError_t e = attention_launch(p, s);
@@ -202,14 +236,31 @@ static GemmArgs u_qkv_args(const uint16_t* A, int64_t lda, const ULin& l, int M,
     return p;
 }
 
-// diffusers Transformer2DModel (use_linear_projection, one BasicTransformerBlock), in place on x f32 [H*W][C].
+// h += gate * (att . W^T + b)   (gate: a constant per-column vector, or null for 1)
+static int u_gemm_resid(const uint16_t* A, int64_t lda, const ULin& l, float* C, int64_t ldc, int M, const float* gate, hipStream_t s) {
+    GemmArgs p{};
+    p.A = A; p.lda = lda; p.W = l.w; p.ldw = l.K; p.bias = l.b; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = l.N; p.K = l.K; p.epi = EPI_RESID_F32;
+    p.gate = gate; p.strideGate = 0;
+    hipError_t e = gemm_launch(p, 1, s);
+    if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet residual)");
+    return R3G_OK;
+}
+
+// diffusers Transformer2DModel (use_linear_projection, one BasicTransformerBlock), in place on x f32 [nb][H*W][C].
 // Fused projection weights are registered by r3g/unet.py (pure re-layouts): attn1.to_qkv = cat(to_q, to_k, to_v) rows,
 // attn2.to_kv = per head (k rows, v rows) of to_k / to_v.
+// With nb > 1 samples (the views of one object) and the weights of upstream's Basic2p5DTransformerBlock registered
+// ([UPSTREAM-RECALLED] hy3dgen/texgen/hunyuanpaint/unet/modules.py) the block also runs, all on norm1's output:
+//   * mv_flags & 1 ("w"): the normalised hidden states of all samples are kept per transformer (condition_embed_dict);
+//   * mv_flags & 2 ("r") and "<blk>.attn_refview.*": h += ref_scale * attn_refview(norm_h, K / V from the kept states of the
+//     reference pass, registered as "cond:<prefix>");
+//   * nb > 1 and "<blk>.attn_multiview.*": h += mva_scale * self-attention over the tokens of ALL views as one sequence.
 static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, int W, int C, const uint16_t* ctx, int tokens,
-                            hipStream_t s) {
-    U_RC(u_check_shape(u, H, W, C, "r3g_unet_transformer"));
+                            hipStream_t s, int nb = 1) {
+    U_RC(u_check_shape(u, H, W, C, "r3g_unet_transformer", nb));
     if (tokens < 1 || tokens > u.c.ctx_tokens) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: %d context tokens (max %d)", tokens, u.c.ctx_tokens);
-    const int hw = H * W, heads = C / 64, Lp = (int)rup(hw, 128), Lkp = (int)rup(tokens, 64);
+    const int hw = H * W, rows = nb * hw, heads = C / 64, Lp = (int)rup(hw, 128), Lkp = (int)rup(tokens, 64), Lall = (int)rup(rows, 128);
     const std::string blk = pre + ".transformer_blocks.0";
     const float *gw, *gb, *w1, *b1, *w2, *b2, *w3, *b3;
     U_RC(u_vec(u, pre + ".norm.weight", C, &gw));
@@ -230,70 +281,118 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
     U_RC(u_lin(u, blk + ".attn2.to_out.0", true, C, C, &o2));
     U_RC(u_lin(u, blk + ".ff.net.0.proj", true, 8 * C, C, &f0));
     U_RC(u_lin(u, blk + ".ff.net.2", true, C, 4 * C, &f2));
+    const bool has_mv = nb > 1 && u.w.count(blk + ".attn_multiview.to_qkv.weight");
+    const auto cond_it = u.w.find("cond:" + pre);
+    const bool has_ref = (u.mv_flags & 2) && cond_it != u.w.end() && u.w.count(blk + ".attn_refview.to_q.weight");
+    if (nb * (int64_t)Lp > Lall + 128 * kMaxViews) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: padded query rows exceed the arena");
     // norm (GroupNorm, no activation) -> proj_in -> hidden state h
-    U_TRY(group_norm_launch(x, hw, C, u.c.groups, gw, gb, 1e-6f, 0, u.xn, u.gn_partial, s));
-    U_RC(u_gemm(u.xn, C, pin, pin.b, u.h, C, hw, EPI_F32, s));
-    // self-attention
-    U_RC(u_layernorm(u.h, u.xn, hw, C, w1, b1, 1e-5f, s));
+    U_RC(u_group_norm(u, x, hw, C, gw, gb, 1e-6f, 0, u.xn, s, nb));
+    U_RC(u_gemm(u.xn, C, pin, pin.b, u.h, C, rows, EPI_F32, s));
+    // self-attention, every sample on its own: the GEMM's batch dimension puts sample n into attention batch n
+    U_RC(u_layernorm(u.h, u.xn, rows, C, w1, b1, 1e-5f, s));
     {
-        const GemmArgs p = u_qkv_args(u.xn, C, qkv, hw, heads, QKV_KHD, u.Q, u.K, u.Vt, Lp, Lp);
-        hipError_t e = gemm_launch(p, 1, s);
+        GemmArgs p = u_qkv_args(u.xn, C, qkv, hw, heads, QKV_KHD, u.Q, u.K, u.Vt, Lp, Lp);
+        p.strideA = (int64_t)hw * C;
+        hipError_t e = gemm_launch(p, nb, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet qkv)");
     }
-    U_RC(u_attention(u, heads, hw, Lp, hw, Lp, u.K, u.Vt, C, s));
-    U_RC(u_gemm(u.att, C, o1, o1.b, u.h, C, hw, EPI_RESID_F32, s));
-    // cross-attention over the context tokens
-    U_RC(u_layernorm(u.h, u.xn, hw, C, w2, b2, 1e-5f, s));
+    U_RC(u_attention(u, heads, hw, Lp, hw, Lp, u.K, u.Vt, C, s, nb));
+    U_RC(u_gemm_resid(u.att, C, o1, u.h, C, rows, nullptr, s));
+    if (u.mv_flags & 1) {          // "w": keep norm1's output of all samples, tokens (n l)
+        Unet::Cond& c = u.cond[pre];
+        const size_t need = (size_t)rows * C * 2;
+        if (need > c.cap) {
+            if (c.p) { U_TRY(hipStreamSynchronize(s)); (void)hipFree(c.p); c.p = nullptr; c.cap = 0; }
+            U_TRY(hipMalloc((void**)&c.p, need));
+            c.cap = need;
+        }
+        c.rows = rows; c.cols = C;
+        U_TRY(hipMemcpyAsync(c.p, u.xn, need, hipMemcpyDeviceToDevice, s));
+    }
+    if (has_ref) {                 // reference attention: every view's tokens query the reference pass's tokens
+        const UTensor& ct = cond_it->second;
+        if (ct.dtype != 1 || ct.cols != C || ct.rows < 1 || ct.rows > u.c.ctx_tokens)
+            return fail(R3G_ERR_INVALID, "r3g_unet_transformer: 'cond:%s' must be bf16 [tokens <= ctx_tokens %d][%d]", pre.c_str(), u.c.ctx_tokens, C);
+        const int rt = (int)ct.rows, Lrp = (int)rup(rt, 64);
+        ULin rq, rkv, ro;
+        U_RC(u_lin(u, blk + ".attn_refview.to_q", false, C, C, &rq));
+        U_RC(u_lin(u, blk + ".attn_refview.to_kv", false, 2 * C, C, &rkv));
+        U_RC(u_lin(u, blk + ".attn_refview.to_out.0", true, C, C, &ro));
+        const GemmArgs pq = u_qkv_args(u.xn, C, rq, rows, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
+        hipError_t e = gemm_launch(pq, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet refview q)");
+        const GemmArgs pk = u_qkv_args((const uint16_t*)ct.p, C, rkv, rt, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lrp);
+        e = gemm_launch(pk, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet refview kv)");
+        U_RC(u_attention(u, heads, rows, Lall, rt, Lrp, u.ctxK, u.ctxVt, C, s));
+        U_RC(u_gemm_resid(u.att, C, ro, u.h, C, rows, u.ref_scale != 1.0f ? u.gate + u.c.max_channels : nullptr, s));
+    }
+    if (has_mv) {                  // multiview attention: the tokens of all views form one sequence
+        ULin mq, mo;
+        U_RC(u_lin(u, blk + ".attn_multiview.to_qkv", false, 3 * C, C, &mq));
+        U_RC(u_lin(u, blk + ".attn_multiview.to_out.0", true, C, C, &mo));
+        const GemmArgs p = u_qkv_args(u.xn, C, mq, rows, heads, QKV_KHD, u.Q, u.K, u.Vt, Lall, Lall);
+        hipError_t e = gemm_launch(p, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet multiview qkv)");
+        U_RC(u_attention(u, heads, rows, Lall, rows, Lall, u.K, u.Vt, C, s));
+        U_RC(u_gemm_resid(u.att, C, mo, u.h, C, rows, u.mva_scale != 1.0f ? u.gate : nullptr, s));
+    }
+    // cross-attention over the context tokens (the same context for every sample: all rows are one batch of queries)
+    U_RC(u_layernorm(u.h, u.xn, rows, C, w2, b2, 1e-5f, s));
     {
-        const GemmArgs pq = u_qkv_args(u.xn, C, q2, hw, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lp, 0);
+        const GemmArgs pq = u_qkv_args(u.xn, C, q2, rows, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
         hipError_t e = gemm_launch(pq, 1, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet q)");
         const GemmArgs pk = u_qkv_args(ctx, u.c.ctx_dim, kv2, tokens, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lkp);
         e = gemm_launch(pk, 1, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet kv)");
     }
-    U_RC(u_attention(u, heads, hw, Lp, tokens, Lkp, u.ctxK, u.ctxVt, C, s));
-    U_RC(u_gemm(u.att, C, o2, o2.b, u.h, C, hw, EPI_RESID_F32, s));
+    U_RC(u_attention(u, heads, rows, Lall, tokens, Lkp, u.ctxK, u.ctxVt, C, s));
+    U_RC(u_gemm_resid(u.att, C, o2, u.h, C, rows, nullptr, s));
     // GEGLU feed-forward
-    U_RC(u_layernorm(u.h, u.xn, hw, C, w3, b3, 1e-5f, s));
-    U_RC(u_gemm(u.xn, C, f0, f0.b, u.ff, 8 * (int64_t)C, hw, EPI_BF16, s));
-    U_TRY(geglu_launch(u.ff, 8 * (int64_t)C, u.ff2, 4 * (int64_t)C, hw, 4 * C, s));
-    U_RC(u_gemm(u.ff2, 4 * (int64_t)C, f2, f2.b, u.h, C, hw, EPI_RESID_F32, s));
+    U_RC(u_layernorm(u.h, u.xn, rows, C, w3, b3, 1e-5f, s));
+    U_RC(u_gemm(u.xn, C, f0, f0.b, u.ff, 8 * (int64_t)C, rows, EPI_BF16, s));
+    U_TRY(geglu_launch(u.ff, 8 * (int64_t)C, u.ff2, 4 * (int64_t)C, rows, 4 * C, s));
+    U_RC(u_gemm_resid(u.ff2, 4 * (int64_t)C, f2, u.h, C, rows, nullptr, s));
     // proj_out + the block's input
-    U_TRY(f32_to_bf16_launch(u.h, u.xn, (int64_t)hw * C, s));
-    return u_gemm(u.xn, C, pout, pout.b, x, C, hw, EPI_RESID_F32, s);
+    U_TRY(f32_to_bf16_launch(u.h, u.xn, (int64_t)rows * C, s));
+    return u_gemm_resid(u.xn, C, pout, x, C, rows, nullptr, s);
 }
 
 // diffusers Downsample2D (conv 3x3, stride 2, padding 1)
-static int unet_downsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s) {
-    U_RC(u_check_shape(u, H, W, C, "r3g_unet_downsample"));
+static int unet_downsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s, int nb = 1) {
+    U_RC(u_check_shape(u, H, W, C, "r3g_unet_downsample", nb));
     ULin cv;
     U_RC(u_lin(u, pre + ".conv", true, C, 9 * C, &cv));
-    U_TRY(f32_to_bf16_launch(x, u.xn, (int64_t)H * W * C, s));
-    return u_conv3x3(u, u.xn, H, W, C, 2, cv, cv.b, out, EPI_F32, s);
+    U_TRY(f32_to_bf16_launch(x, u.xn, (int64_t)nb * H * W * C, s));
+    return u_conv3x3(u, u.xn, H, W, C, 2, cv, cv.b, out, EPI_F32, s, 1, nb);
 }
 
 // diffusers Upsample2D: nearest 2x, then conv 3x3 (padding 1)
-static int unet_upsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s) {
-    U_RC(u_check_shape(u, 2 * H, 2 * W, C, "r3g_unet_upsample"));
+static int unet_upsample(Unet& u, const std::string& pre, const float* x, int H, int W, int C, float* out, hipStream_t s, int nb = 1) {
+    U_RC(u_check_shape(u, 2 * H, 2 * W, C, "r3g_unet_upsample", nb));
     ULin cv;
     U_RC(u_lin(u, pre + ".conv", true, C, 9 * C, &cv));
-    U_TRY(upsample2x_launch(x, H, W, C, u.xn, s));
-    return u_conv3x3(u, u.xn, 2 * H, 2 * W, C, 1, cv, cv.b, out, EPI_F32, s);
+    for (int n = 0; n < nb; ++n)
+        U_TRY(upsample2x_launch(x + (int64_t)n * H * W * C, H, W, C, u.xn + (int64_t)n * 4 * H * W * C, s));
+    return u_conv3x3(u, u.xn, 2 * H, 2 * W, C, 1, cv, cv.b, out, EPI_F32, s, 1, nb);
 }
 
 // diffusers UNet2DConditionModel.forward on the SD-2.1 layout: conv_in, time embedding, CrossAttnDownBlock2D x (n-1) +
 // DownBlock2D, UNetMidBlock2DCrossAttn, UpBlock2D + CrossAttnUpBlock2D x (n-1) (every resnet of the up path takes
-// cat(hidden, skip)), conv_norm_out + SiLU + conv_out.  sample f32 [H*W][in_channels] -> out f32 [H*W][out_channels].
+// cat(hidden, skip)), conv_norm_out + SiLU + conv_out.  sample f32 [nb][H*W][in_channels] -> out f32 [nb][H*W][out_channels].
+// labels (host, [nb], or null): class_labels -- emb_n = time_embedding(t) + class_embedding.weight[labels[n]] (diffusers
+// class_embed_type None with an nn.Embedding put in its place: the camera embedding of upstream's multiview UNet).
 static int unet_forward(Unet& u, const float* sample, int H, int W, float timestep, const uint16_t* ctx, int tokens, float* out,
-                        hipStream_t s) {
+                        hipStream_t s, int nb = 1, const int32_t* labels = nullptr) {
     const r3g_unet_config& c = u.c;
     const int n = c.n_levels, L = c.layers_per_block;
     if (n < 1 || n > 4 || L < 1) return fail(R3G_ERR_STATE, "r3g_unet_forward: the configuration has no block structure");
     if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) return fail(R3G_ERR_INVALID, "r3g_unet_forward: %d x %d is not divisible by %d", H, W, 1 << (n - 1));
     const int* ch = c.block_out_channels;
     const int c0 = ch[0];
-    U_RC(u_check_shape(u, H, W, c0, "r3g_unet_forward"));
+    U_RC(u_check_shape(u, H, W, c0, "r3g_unet_forward", nb));
+    u.nb = nb;
     // skip stack: conv_in output + every state of the down path
     struct Skip { float* p; int c, h, w; };
     std::vector<Skip> stack;
@@ -305,7 +404,7 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
             need += (size_t)L * h * w * ch[i];
             if (i < n - 1) { h /= 2; w /= 2; need += (size_t)h * w * ch[i]; }
         }
-        need *= 4;
+        need *= 4 * (size_t)nb;
         if (need > u.skips_bytes) {
             if (u.skips) { U_TRY(hipStreamSynchronize(s)); (void)hipFree(u.skips); u.skips = nullptr; u.skips_bytes = 0; }
             U_TRY(hipMalloc((void**)&u.skips, need));
@@ -313,7 +412,7 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
         }
     }
     float* next_slot = u.skips;
-    auto push = [&](int cc, int h, int w) { Skip k{next_slot, cc, h, w}; next_slot += (size_t)h * w * cc; stack.push_back(k); return k.p; };
+    auto push = [&](int cc, int h, int w) { Skip k{next_slot, cc, h, w}; next_slot += (size_t)nb * h * w * cc; stack.push_back(k); return k.p; };
     // time embedding: Timesteps(c0) -> linear_1 -> SiLU -> linear_2
     ULin l1, l2;
     U_RC(u_lin(u, "time_embedding.linear_1", true, c.temb_dim, c0, &l1));
@@ -322,14 +421,28 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
     U_TRY(unet_timestep_launch(timestep, c0, tsin, s));
     U_TRY(gemv_launch(tsin, 1, c0, l1.w, l1.K, l1.b, u.t1 /* scratch */, c.temb_dim, 0, 1, s));
     U_TRY(gemv_launch(u.t1, 1, c.temb_dim, l2.w, l2.K, l2.b, u.emb, c.temb_dim, 0, 0, s));
+    const float* emb = u.emb;
+    int64_t emb_stride = 0;
+    if (labels) {
+        auto it = u.w.find("class_embedding.weight");
+        if (it == u.w.end() || it->second.dtype != 0 || it->second.cols != c.temb_dim)
+            return fail(R3G_ERR_STATE, "r3g_unet_forward: class labels need 'class_embedding.weight' as f32 [classes][%d]", c.temb_dim);
+        for (int k = 0; k < nb; ++k) {
+            if (labels[k] < 0 || labels[k] >= it->second.rows) return fail(R3G_ERR_INVALID, "r3g_unet_forward: class label %d out of range", labels[k]);
+            U_TRY(vec_add_launch(u.emb, (const float*)it->second.p + (int64_t)labels[k] * c.temb_dim, u.embn + (int64_t)k * c.temb_dim,
+                                 c.temb_dim, s));
+        }
+        emb = u.embn;
+        emb_stride = c.temb_dim;
+    }
     // conv_in (input channels zero-padded to 64 in the operand and in the re-laid weight)
     {
         ULin ci;
         U_RC(u_lin(u, "conv_in", true, c0, 9 * 64, &ci));
         if (c.in_channels < 1 || c.in_channels > 64) return fail(R3G_ERR_INVALID, "r3g_unet_forward: in_channels must be in [1, 64]");
-        U_TRY(cast_pad_launch(sample, c.in_channels, u.xn, 64, H * W, c.in_channels, 64, 1.0f, s));
+        U_TRY(cast_pad_launch(sample, c.in_channels, u.xn, 64, nb * H * W, c.in_channels, 64, 1.0f, s));
         float* x0 = push(c0, H, W);
-        U_RC(u_conv3x3(u, u.xn, H, W, 64, 1, ci, ci.b, x0, EPI_F32, s));
+        U_RC(u_conv3x3(u, u.xn, H, W, 64, 1, ci, ci.b, x0, EPI_F32, s, 1, nb));
     }
     const float* cur = stack.back().p;
     int h = H, w = W, cc = c0;
@@ -338,23 +451,23 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
         const std::string pre = "down_blocks." + std::to_string(i);
         for (int j = 0; j < L; ++j) {
             float* dst = push(ch[i], h, w);
-            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), cur, h, w, cc, ch[i], u.emb, dst, s));
-            if (!last) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), dst, h, w, ch[i], ctx, tokens, s));
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), cur, h, w, cc, ch[i], emb, dst, s, nb, emb_stride));
+            if (!last) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), dst, h, w, ch[i], ctx, tokens, s, nb));
             cur = dst;
             cc = ch[i];
         }
         if (!last) {
             float* dst = push(cc, h / 2, w / 2);
-            U_RC(unet_downsample(u, pre + ".downsamplers.0", cur, h, w, cc, dst, s));
+            U_RC(unet_downsample(u, pre + ".downsamplers.0", cur, h, w, cc, dst, s, nb));
             cur = dst;
             h /= 2; w /= 2;
         }
     }
     // mid block
     int side = 0;
-    U_RC(unet_resnet(u, "mid_block.resnets.0", cur, h, w, cc, cc, u.emb, u.hb[side], s));
-    U_RC(unet_transformer(u, "mid_block.attentions.0", u.hb[side], h, w, cc, ctx, tokens, s));
-    U_RC(unet_resnet(u, "mid_block.resnets.1", u.hb[side], h, w, cc, cc, u.emb, u.hb[side], s));
+    U_RC(unet_resnet(u, "mid_block.resnets.0", cur, h, w, cc, cc, emb, u.hb[side], s, nb, emb_stride));
+    U_RC(unet_transformer(u, "mid_block.attentions.0", u.hb[side], h, w, cc, ctx, tokens, s, nb));
+    U_RC(unet_resnet(u, "mid_block.resnets.1", u.hb[side], h, w, cc, cc, emb, u.hb[side], s, nb, emb_stride));
     cur = u.hb[side];
     // up path
     for (int i = 0; i < n; ++i) {
@@ -367,18 +480,18 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
             if (sk.h != h || sk.w != w) return fail(R3G_ERR_STATE, "r3g_unet_forward: skip resolution mismatch");
             const int cin = cc + sk.c;
             if (cin > c.max_channels) return fail(R3G_ERR_INVALID, "r3g_unet_forward: %d concatenated channels exceed max_channels", cin);
-            const size_t hwn = (size_t)h * w;
+            const size_t hwn = (size_t)nb * h * w;
             U_TRY(hipMemcpy2DAsync(u.catbuf, (size_t)cin * 4, cur, (size_t)cc * 4, (size_t)cc * 4, hwn, hipMemcpyDeviceToDevice, s));
             U_TRY(hipMemcpy2DAsync(u.catbuf + cc, (size_t)cin * 4, sk.p, (size_t)sk.c * 4, (size_t)sk.c * 4, hwn, hipMemcpyDeviceToDevice, s));
             side ^= 1;
-            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), u.catbuf, h, w, cin, cout, u.emb, u.hb[side], s));
-            if (i > 0) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), u.hb[side], h, w, cout, ctx, tokens, s));
+            U_RC(unet_resnet(u, pre + ".resnets." + std::to_string(j), u.catbuf, h, w, cin, cout, emb, u.hb[side], s, nb, emb_stride));
+            if (i > 0) U_RC(unet_transformer(u, pre + ".attentions." + std::to_string(j), u.hb[side], h, w, cout, ctx, tokens, s, nb));
             cur = u.hb[side];
             cc = cout;
         }
         if (i < n - 1) {
             side ^= 1;
-            U_RC(unet_upsample(u, pre + ".upsamplers.0", cur, h, w, cc, u.hb[side], s));
+            U_RC(unet_upsample(u, pre + ".upsamplers.0", cur, h, w, cc, u.hb[side], s, nb));
             cur = u.hb[side];
             h *= 2; w *= 2;
         }
@@ -389,8 +502,8 @@ static int unet_forward(Unet& u, const float* sample, int H, int W, float timest
     U_RC(u_vec(u, "conv_norm_out.bias", c0, &gb));
     ULin co;
     U_RC(u_lin(u, "conv_out", true, c.out_channels, 9 * c0, &co));
-    U_TRY(group_norm_launch(cur, H * W, c0, c.groups, gw, gb, 1e-5f, 1, u.xn, u.gn_partial, s));
-    return u_conv3x3(u, u.xn, H, W, c0, 1, co, co.b, out, EPI_F32, s);
+    U_RC(u_group_norm(u, cur, H * W, c0, gw, gb, 1e-5f, 1, u.xn, s, nb));
+    return u_conv3x3(u, u.xn, H, W, c0, 1, co, co.b, out, EPI_F32, s, 1, nb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -557,6 +670,8 @@ static void unet_free(Unet* u) {
     if (!u) return;
     if (u->arena) (void)hipFree(u->arena);
     if (u->skips) (void)hipFree(u->skips);
+    for (auto& kv : u->cond)
+        if (kv.second.p) (void)hipFree(kv.second.p);
     delete u;
 }
 
@@ -568,7 +683,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
         return fail(R3G_ERR_INVALID, "r3g_unet_create: bad configuration");
     Unet* u = new Unet();
     u->c = c;
-    const int64_t hw = c.max_hw, hwp = rup(hw, 128), C = c.max_channels, heads = C / 64, ckp = rup(c.ctx_tokens, 64);
+    const int64_t hw = c.max_hw, hwp = rup(hw, 128) + 128 * kMaxViews, C = c.max_channels, heads = C / 64, ckp = rup(c.ctx_tokens, 64);
     size_t off = 0;
     auto carve = [&](int64_t bytes) { size_t o = off; off += (size_t)rup(bytes, 256); return o; };
     const size_t o_h = carve(hw * C * 4), o_t1 = carve(hw * C * 4), o_xn = carve(hw * C * 2), o_col = carve(hw * 9 * C * 2),
@@ -576,7 +691,8 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
                  o_att = carve(hw * C * 2), o_ff = carve(hw * 8 * C * 2), o_ff2 = carve(hw * 4 * C * 2),
                  o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
                  o_gn = carve(256LL * 256 * 2 * 8), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
-                 o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4);
+                 o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4), o_vecn = carve((int64_t)kMaxViews * C * 4),
+                 o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4);
     hipError_t e = hipMalloc((void**)&u->arena, off);
     if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMalloc(unet arena)"); }
     e = hipMemset(u->arena, 0, off);      // padded rows must start finite
@@ -587,6 +703,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     u->ff = (uint16_t*)(a + o_ff); u->ff2 = (uint16_t*)(a + o_ff2); u->ctxK = (uint16_t*)(a + o_ck); u->ctxVt = (uint16_t*)(a + o_cv);
     u->vec = (float*)(a + o_vec); u->gn_partial = (double*)(a + o_gn);
     u->catbuf = (float*)(a + o_cat); u->hb[0] = (float*)(a + o_hb0); u->hb[1] = (float*)(a + o_hb1); u->emb = (float*)(a + o_emb);
+    u->vecn = (float*)(a + o_vecn); u->embn = (float*)(a + o_embn); u->gate = (float*)(a + o_gate);
     ctx->unet = u;
     return R3G_OK;
 }
@@ -670,7 +787,55 @@ int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width,
                      float* d_out, void* stream) {
     NEED_UNET("r3g_unet_forward");
     if (!d_sample || !d_ctx || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_forward: null argument");
+    u->mv_flags = 0;
     return unet_forward(*u, d_sample, height, width, timestep, d_ctx, tokens, d_out, (hipStream_t)stream);
+}
+
+// the constant gate vectors of the 2.5D attention branches (mva_scale | ref_scale) and the mode of the pass
+static int mv_begin(Unet& u, int n_views, int flags, float mva_scale, float ref_scale, hipStream_t s, const char* fn) {
+    if (n_views < 1 || n_views > kMaxViews) return fail(R3G_ERR_INVALID, "%s: n_views must be in [1, %d]", fn, kMaxViews);
+    if (flags & ~3) return fail(R3G_ERR_INVALID, "%s: flags is a combination of 1 (write the reference states) and 2 (read them)", fn);
+    u.mv_flags = flags; u.mva_scale = mva_scale; u.ref_scale = ref_scale;
+    uint32_t bits[2];
+    std::memcpy(&bits[0], &mva_scale, 4);
+    std::memcpy(&bits[1], &ref_scale, 4);
+    U_TRY(hipMemsetD32Async((hipDeviceptr_t)u.gate, (int)bits[0], (size_t)u.c.max_channels, s));
+    U_TRY(hipMemsetD32Async((hipDeviceptr_t)(u.gate + u.c.max_channels), (int)bits[1], (size_t)u.c.max_channels, s));
+    return R3G_OK;
+}
+
+int r3g_unet_forward_mv(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
+                        int n_views, const int32_t* class_labels, int flags, float mva_scale, float ref_scale, float* d_out,
+                        void* stream) {
+    NEED_UNET("r3g_unet_forward_mv");
+    if (!d_sample || !d_ctx || !d_out) return fail(R3G_ERR_INVALID, "r3g_unet_forward_mv: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = mv_begin(*u, n_views, flags, mva_scale, ref_scale, s, "r3g_unet_forward_mv");
+    if (rc) return rc;
+    rc = unet_forward(*u, d_sample, height, width, timestep, d_ctx, tokens, d_out, s, n_views, class_labels);
+    u->mv_flags = 0;
+    return rc;
+}
+
+int r3g_unet_transformer_mv(r3g_ctx* ctx, const char* prefix, float* d_x, int height, int width, int channels, const uint16_t* d_ctx,
+                            int tokens, int n_views, int flags, float mva_scale, float ref_scale, void* stream) {
+    NEED_UNET("r3g_unet_transformer_mv");
+    if (!prefix || !d_x || !d_ctx) return fail(R3G_ERR_INVALID, "r3g_unet_transformer_mv: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = mv_begin(*u, n_views, flags, mva_scale, ref_scale, s, "r3g_unet_transformer_mv");
+    if (rc) return rc;
+    rc = unet_transformer(*u, prefix, d_x, height, width, channels, d_ctx, tokens, s, n_views);
+    u->mv_flags = 0;
+    return rc;
+}
+
+int r3g_unet_condition(r3g_ctx* ctx, const char* prefix, const void** d_ptr, int64_t* rows, int64_t* cols) {
+    NEED_UNET("r3g_unet_condition");
+    if (!prefix || !d_ptr || !rows || !cols) return fail(R3G_ERR_INVALID, "r3g_unet_condition: null argument");
+    auto it = u->cond.find(prefix);
+    if (it == u->cond.end() || !it->second.p) return fail(R3G_ERR_STATE, "r3g_unet_condition: no pass with flag 1 has written '%s'", prefix);
+    *d_ptr = it->second.p; *rows = it->second.rows; *cols = it->second.cols;
+    return R3G_OK;
 }
 
 int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,

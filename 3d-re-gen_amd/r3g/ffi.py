@@ -65,6 +65,9 @@ SYMBOLS = {
     "r3g_unet_down_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "r3g_unet_forward": (_I, [_P, _P, _I, _I, ctypes.c_float, _P, _I, _P, _P]),
     "r3g_unet_mid_block": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "r3g_unet_forward_mv": (_I, [_P, _P, _I, _I, ctypes.c_float, _P, _I, _I, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P]),
+    "r3g_unet_transformer_mv": (_I, [_P, ctypes.c_char_p, _P, _I, _I, _I, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "r3g_unet_condition": (_I, [_P, ctypes.c_char_p, _P, _P, _P]),
     "r3g_aekl_decode": (_I, [_P, _P, _I, _I, _P, _P]),
     "r3g_aekl_encode": (_I, [_P, _P, _I, _I, _P, _P]),
     "r3g_sched_pix2pix_input": (_I, [_P, _P, _I, ctypes.c_int64, ctypes.c_float, _P, _P]),

@@ -15,17 +15,24 @@ from . import ffi as _l
 
 
 def prepare_weights(sd, device):
-    """pure re-layouts: 3x3 conv [O][I][3][3] -> [O][ky][kx][I]; 1x1 conv -> [O][I]; attn1 to_q|to_k|to_v -> to_qkv rows;
-    attn2 to_k / to_v -> per head (64 k rows, 64 v rows); matrices bf16, vectors f32"""
+    """pure re-layouts: 3x3 conv [O][I][3][3] -> [O][ky][kx][I]; 1x1 conv -> [O][I]; self-attentions (attn1, attn_multiview)
+    to_q|to_k|to_v -> to_qkv rows; cross-attentions (attn2, attn_refview) to_k / to_v -> per head (64 k rows, 64 v rows), to_q
+    kept; matrices bf16, vectors f32; "class_embedding.weight" stays an f32 table; the learned text embeddings are inputs of
+    the model, not weights of the library (skipped)"""
     out = {}
     groups = {}
     for k, t in sd.items():
+        if "learned_text_clip" in k:
+            continue
         t = t.detach().to(torch.float32)
+        if k == "class_embedding.weight":
+            out[k] = (t.to(device=device).contiguous(), 0)
+            continue
         base, leaf = k.rsplit(".", 1)
         parent, name = base.rsplit(".", 1) if "." in base else ("", base)
         if name in ("to_q", "to_k", "to_v") and leaf == "weight":
             groups.setdefault(parent, {})[name] = t
-            if name == "to_q" and parent.endswith("attn2"):
+            if name == "to_q" and not parent.endswith(("attn1", "attn_multiview")):
                 out[k] = (t.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
             continue
         if t.ndim == 4:
@@ -42,7 +49,7 @@ def prepare_weights(sd, device):
         else:
             out[k] = (t.reshape(1, -1).to(device=device).contiguous(), 0)
     for parent, g in groups.items():
-        if parent.endswith("attn1"):
+        if parent.endswith(("attn1", "attn_multiview")):
             w = torch.cat([g["to_q"], g["to_k"], g["to_v"]], dim=0)
             out[parent + ".to_qkv.weight"] = (w.to(device=device, dtype=torch.bfloat16).contiguous(), 1)
         else:
@@ -53,13 +60,43 @@ def prepare_weights(sd, device):
     return out
 
 
+def split_2p5d_state_dict(sd):
+    """state dict of upstream's UNet2p5DConditionModel ([UPSTREAM-RECALLED] names: "unet.*" with the wrapped blocks'
+    parameters under "...transformer_blocks.0.transformer.*", "unet_dual.*" likewise) -> (generator weights, reference-copy
+    weights, {"learned_text_clip_gen", "learned_text_clip_ref"}) under the plain diffusers names the library registers"""
+    gen, ref, extra = {}, {}, {}
+    for k, v in sd.items():
+        if k.startswith("unet_dual."):
+            dst, name = ref, k[len("unet_dual."):]
+        elif k.startswith("unet."):
+            dst, name = gen, k[len("unet."):]
+        else:
+            continue
+        if name.startswith("learned_text_clip"):
+            extra[name] = v
+            continue
+        dst[name.replace(".transformer_blocks.0.transformer.", ".transformer_blocks.0.")] = v
+    return gen, ref, extra
+
+
+def transformer_prefixes(n_levels, layers_per_block=2):
+    """names of the Transformer2DModels of the SD-2.1 layout (the keys of the reference pass's kept states)"""
+    out = []
+    for i in range(n_levels - 1):
+        out += ["down_blocks.%d.attentions.%d" % (i, j) for j in range(layers_per_block)]
+    out.append("mid_block.attentions.0")
+    for i in range(1, n_levels):
+        out += ["up_blocks.%d.attentions.%d" % (i, j) for j in range(layers_per_block + 1)]
+    return out
+
+
 def to_rows(x):
-    """NCHW [1, C, H, W] -> rows f32 [H*W, C]"""
-    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).to(torch.float32).contiguous()
+    """NCHW [n, C, H, W] -> rows f32 [n*H*W, C] (sample after sample)"""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).to(torch.float32).contiguous()
 
 
-def from_rows(r, h, w):
-    return r.reshape(h, w, -1).permute(2, 0, 1)[None].contiguous()
+def from_rows(r, h, w, n=1):
+    return r.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
 
 class UnetBlocks:
@@ -155,6 +192,45 @@ class UnetBlocks:
             _l.check(self.L.r3g_unet_forward(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), ctx_rows.data_ptr(),
                                              ctx_rows.shape[0], out.data_ptr(), self._s()))
         return out
+
+    # ---- several samples per call, 2.5D blocks (include/r3g.h "several samples per call ...")
+    def forward_mv(self, sample, timestep, ctx, class_labels=None, flags=0, mva_scale=1.0, ref_scale=1.0):
+        """sample NCHW [n, in_channels, H, W] (the n views of ONE object) -> NCHW [n, out_channels, H, W]; ctx [1, tokens, dim]
+        shared by the views; class_labels: n camera indices or None; flags 1 = keep the states for reference attention
+        (the reference pass), 2 = use the registered ones (set_condition)"""
+        n, cin, h, w = sample.shape
+        rows, _, cx = self._in(sample, None, ctx)
+        out = torch.empty((n * h * w, self.out_channels), dtype=torch.float32, device=self.device)
+        lab = None
+        if class_labels is not None:
+            lab = (ctypes.c_int32 * n)(*[int(v) for v in class_labels])
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_forward_mv(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), cx.data_ptr(),
+                                                cx.shape[0], n, lab, int(flags), ctypes.c_float(float(mva_scale)),
+                                                ctypes.c_float(float(ref_scale)), out.data_ptr(), self._s()))
+        return from_rows(out, h, w, n)
+
+    def transformer_mv(self, prefix, x, ctx, flags=0, mva_scale=1.0, ref_scale=1.0):
+        n, c, h, w = x.shape
+        rows, _, cx = self._in(x, None, ctx)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_transformer_mv(self.ctx, prefix.encode(), rows.data_ptr(), h, w, c, cx.data_ptr(), cx.shape[0],
+                                                    n, int(flags), ctypes.c_float(float(mva_scale)),
+                                                    ctypes.c_float(float(ref_scale)), self._s()))
+        return from_rows(rows, h, w, n)
+
+    def condition(self, prefix):
+        """(device pointer, rows, cols) of what the last pass with flag 1 kept for the transformer `prefix`"""
+        p, r, c = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _l.check(self.L.r3g_unet_condition(self.ctx, prefix.encode(), ctypes.byref(p), ctypes.byref(r), ctypes.byref(c)))
+        return p.value, r.value, c.value
+
+    def set_condition(self, prefix, source):
+        """register the states `source` (another UnetBlocks: the reference copy) kept for `prefix` as this model's "cond:"
+        tensor; the memory stays owned by `source` and is overwritten by its next reference pass (same stream: ordered)"""
+        p, r, c = source.condition(prefix)
+        with torch.cuda.device(self.device):
+            _l.check(self.L.r3g_unet_set_tensor(self.ctx, ("cond:" + prefix).encode(), ctypes.c_void_p(p), 1, r, c))
 
     def mid_block(self, prefix, x, temb, ctx):
         _, c, h, w = x.shape

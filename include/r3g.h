@@ -274,6 +274,31 @@ int r3g_unet_down_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int 
  * d_sample f32 [height*width][in_channels] -> d_out f32 [height*width][out_channels]; height, width divisible by 2^(n-1). */
 int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
                      float* d_out, void* stream);
+/* ---- several samples per call and upstream's 2.5D transformer blocks: the multiview UNet of the texture stage ----
+ * [UPSTREAM-RECALLED] hy3dgen/texgen/hunyuanpaint/unet/modules.py: UNet2p5DConditionModel wraps an SD-2.1 UNet2DConditionModel;
+ * every BasicTransformerBlock becomes a Basic2p5DTransformerBlock with two more attentions on norm1's output --
+ * attn_multiview (self-attention over the tokens of ALL views of the object as one sequence, scaled by mva_scale) and
+ * attn_refview (every view's tokens attend to the normalised hidden states a separate "reference" UNet pass over the input
+ * image has kept per block, scaled by ref_scale) --, conv_in takes 12 channels (latent | normal map latent | position map
+ * latent) and an nn.Embedding over camera indices is added to the time embedding (class_labels).
+ * Samples are stacked as rows: d_sample f32 [n_views][height*width][in_channels], d_out likewise; r3g_unet_create's max_hw
+ * is then the largest n_views*height*width, ctx_tokens at least the number of reference tokens.  Extra tensors
+ * (r3g_unet_set_tensor): "<...>.transformer_blocks.0.attn_multiview.to_qkv.weight" ([3C][C]: to_q | to_k | to_v),
+ * ".attn_multiview.to_out.0.{weight,bias}", ".attn_refview.to_q.weight", ".attn_refview.to_kv.weight" (per head 64 k rows,
+ * 64 v rows), ".attn_refview.to_out.0.{weight,bias}", "class_embedding.weight" (f32 [classes][temb_dim]), and per transformer
+ * "cond:<transformer prefix>" = the reference pass's kept states (bf16 [reference tokens][C], from r3g_unet_condition of the
+ * context that ran the reference pass).  Blocks whose 2.5D weights are not registered run as the plain block.
+ * flags: 1 = keep norm1's output of every transformer ("w" mode, the reference pass), 2 = run attn_refview where its weights
+ * and "cond:" tensor exist ("r" mode).  class_labels: host array [n_views] or NULL. */
+int r3g_unet_forward_mv(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
+                        int n_views, const int32_t* class_labels, int flags, float mva_scale, float ref_scale, float* d_out,
+                        void* stream);
+/* one Transformer2DModel with the 2.5D block, in place on d_x f32 [n_views][height*width][channels] */
+int r3g_unet_transformer_mv(r3g_ctx* ctx, const char* prefix, float* d_x, int height, int width, int channels, const uint16_t* d_ctx,
+                            int tokens, int n_views, int flags, float mva_scale, float ref_scale, void* stream);
+/* what a pass with flag 1 kept for the transformer `prefix` ("down_blocks.0.attentions.1", "mid_block.attentions.0", ...):
+ * bf16 [rows = samples*height*width][cols = channels], owned by the context, valid until its next pass with flag 1 */
+int r3g_unet_condition(r3g_ctx* ctx, const char* prefix, const void** d_ptr, int64_t* rows, int64_t* cols);
 /* UNetMidBlock2DCrossAttn.forward: resnet, transformer, resnet -> d_out f32 [height*width][channels] */
 int r3g_unet_mid_block(r3g_ctx* ctx, const char* prefix, const float* d_x, int height, int width, int channels,
                        const float* d_temb, const uint16_t* d_ctx, int tokens, float* d_out, void* stream);

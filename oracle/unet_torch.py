@@ -264,8 +264,11 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(G, ch[0], eps=1e-5)
         self.conv_out = nn.Conv2d(ch[0], cfg.get("out_channels", 4), 3, padding=1)
 
-    def forward(self, sample, timestep, ctx):
+    def forward(self, sample, timestep, ctx, class_emb=None):
+        """class_emb [B, temb_dim]: diffusers adds the class embedding to the time embedding (emb = emb + class_emb)"""
         emb = self.time_embedding(timestep_embedding(torch.as_tensor([float(timestep)]), self.cfg["block_out_channels"][0]))
+        if class_emb is not None:
+            emb = emb + class_emb
         x = self.conv_in(sample)
         skips = [x]
         for b in self.down_blocks:
