@@ -207,14 +207,23 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 
 // ---- the sampling loop of an InstructPix2Pix-class pipeline (upstream's delighting model), around r3g_unet_forward --------
-// UNet input rows: out[p] = (latent[p] / sqrt(sigma^2 + 1) | image_latent[p])   (scheduler.scale_model_input + torch.cat(dim=1))
-__global__ __launch_bounds__(256) void pix2pix_input_kernel(const float* __restrict__ lat, const float* __restrict__ img, int zc,
-                                                            int64_t n, float inv, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over pixels x 2 zc
-    if (i >= n * 2 * zc) return;
-    const int64_t p = i / (2 * zc);
-    const int c = (int)(i - p * 2 * zc);
-    out[i] = c < zc ? lat[p * zc + c] * inv : img[p * zc + (c - zc)];
+// UNet input rows: out[p] = (latent[p] / sqrt(sigma^2 + 1) | cond[p])   (scheduler.scale_model_input + torch.cat(dim=1)); cond =
+// the image latents (InstructPix2Pix: ic = zc) or the normal- and position-map latents of a view (multiview UNet: ic = 2 zc)
+__global__ __launch_bounds__(256) void model_input_kernel(const float* __restrict__ lat, const float* __restrict__ cond, int zc, int ic,
+                                                          int64_t n, float inv, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over pixels x (zc + ic)
+    const int oc = zc + ic;
+    if (i >= n * oc) return;
+    const int64_t p = i / oc;
+    const int c = (int)(i - p * oc);
+    out[i] = c < zc ? lat[p * zc + c] * inv : cond[p * ic + (c - zc)];
+}
+
+// classifier-free guidance: out = uncond + scale (cond - uncond)
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ u, const float* __restrict__ c, int64_t n, float g,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = u[i] + g * (c[i] - u[i]);
 }
 
 // diffusers EulerAncestralDiscreteScheduler.step, in place on the sample: x0 = x - sigma eps (epsilon) or
@@ -315,11 +324,18 @@ hipError_t softmax_rows_launch(const float* S, int64_t lds, uint16_t* P, int64_t
     return hipGetLastError();
 }
 
-hipError_t pix2pix_input_launch(const float* lat, const float* img, int zc, int64_t pixels, float sigma, float* out, hipStream_t s) {
-    if (zc < 1 || pixels < 1) return hipErrorInvalidValue;
+hipError_t model_input_launch(const float* lat, int zc, const float* cond, int ic, int64_t pixels, float sigma, float* out, hipStream_t s) {
+    if (zc < 1 || ic < 1 || pixels < 1) return hipErrorInvalidValue;
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);
-    hipLaunchKernelGGL(pix2pix_input_kernel, dim3(blocks_for(pixels * 2 * zc, 256)), dim3(256), 0, s, lat, img, zc, pixels, inv, out);
+    hipLaunchKernelGGL(model_input_kernel, dim3(blocks_for(pixels * (zc + ic), 256)), dim3(256), 0, s, lat, cond, zc, ic, pixels, inv, out);
+    return hipGetLastError();
+}
+
+hipError_t cfg_combine_launch(const float* uncond, const float* cond, int64_t n, float scale, float* out, hipStream_t s) {
+    if (n < 1) return hipErrorInvalidValue;
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, uncond, cond, n, scale, out);
     return hipGetLastError();
 }
 

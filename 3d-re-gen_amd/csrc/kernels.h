@@ -215,9 +215,10 @@ hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t 
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);
 // P[r][:] = softmax(scale * S[r][:]) as bf16 (fp32 scores in; n % 4 == 0): the VAE mid block's single-head attention
 hipError_t softmax_rows_launch(const float* S, int64_t lds, uint16_t* P, int64_t ldp, int rows, int n, float scale, hipStream_t s);
-// sampling loop of an InstructPix2Pix-class pipeline: UNet input rows (latent / sqrt(sigma^2 + 1) | image latent), and one
-// EulerAncestralDiscreteScheduler step in place on the sample (vpred: v_prediction instead of epsilon)
-hipError_t pix2pix_input_launch(const float* lat, const float* img, int zc, int64_t pixels, float sigma, float* out, hipStream_t s);
+// sampling loops of the texture stage's diffusion pipelines: UNet input rows (latent / sqrt(sigma^2 + 1) | conditioning latents),
+// classifier-free guidance, and one EulerAncestralDiscreteScheduler step in place on the sample (vpred: v_prediction)
+hipError_t model_input_launch(const float* lat, int zc, const float* cond, int ic, int64_t pixels, float sigma, float* out, hipStream_t s);
+hipError_t cfg_combine_launch(const float* uncond, const float* cond, int64_t n, float scale, float* out, hipStream_t s);
 hipError_t euler_ancestral_step_launch(float* x, const float* model_out, const float* noise, int64_t n, float sigma_from,
                                        float sigma_to, int vpred, hipStream_t s);
 // nearest 2x upsampling: f32 [H][W][C] -> bf16 [2H][2W][C]

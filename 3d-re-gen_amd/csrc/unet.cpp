@@ -863,12 +863,24 @@ int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, f
     return vae_encode(*u, d_image, height, width, d_moments, (hipStream_t)stream);
 }
 
+int r3g_sched_model_input(const float* d_latent, int channels, const float* d_cond, int cond_channels, int64_t pixels, float sigma,
+                          float* d_out, void* stream) {
+    if (!d_latent || !d_cond || !d_out || channels < 1 || cond_channels < 1 || pixels < 1 || !(sigma >= 0.0f))
+        return fail(R3G_ERR_INVALID, "r3g_sched_model_input: bad argument");
+    hipError_t e = model_input_launch(d_latent, channels, d_cond, cond_channels, pixels, sigma, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "model_input_launch");
+    return R3G_OK;
+}
+
 int r3g_sched_pix2pix_input(const float* d_latent, const float* d_image_latent, int channels, int64_t pixels, float sigma,
                             float* d_out, void* stream) {
-    if (!d_latent || !d_image_latent || !d_out || channels < 1 || pixels < 1 || !(sigma >= 0.0f))
-        return fail(R3G_ERR_INVALID, "r3g_sched_pix2pix_input: bad argument");
-    hipError_t e = pix2pix_input_launch(d_latent, d_image_latent, channels, pixels, sigma, d_out, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "pix2pix_input_launch");
+    return r3g_sched_model_input(d_latent, channels, d_image_latent, channels, pixels, sigma, d_out, stream);
+}
+
+int r3g_sched_cfg_combine(const float* d_uncond, const float* d_cond, int64_t n, float guidance_scale, float* d_out, void* stream) {
+    if (!d_uncond || !d_cond || !d_out || n < 1) return fail(R3G_ERR_INVALID, "r3g_sched_cfg_combine: bad argument");
+    hipError_t e = cfg_combine_launch(d_uncond, d_cond, n, guidance_scale, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cfg_combine_launch");
     return R3G_OK;
 }
 

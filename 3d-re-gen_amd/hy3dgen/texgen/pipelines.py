@@ -6,12 +6,16 @@ image-to-image diffusion model -> UV-unwrap the mesh (xatlas) -> render normal /
 native `custom_rasterizer` -> generate the six views with a multiview diffusion UNet -> back-project and blend them into a
 UV texture -> inpaint what no view saw (`mesh_processor.meshVerticeInpaint` + cv2) -> textured mesh.
 
-What exists here (partial): everything EXCEPT the multiview diffusion model.  The delighting model
-(`delight_model=`: hy3dgen.texgen.utils.dehighlight_utils.Light_Shadow_Remover -- SD-2.x UNet, SD VAE and Euler-ancestral loop on
-the HIP blocks) runs when the caller has its checkpoint; without one the input image is used as it is.  The native pieces run as HIP
+What exists here: every step, the two diffusion models included -- but no checkpoint for either, and what
+is recalled of upstream's code is not pinned against it.  The delighting model (`delight_model=`:
+hy3dgen.texgen.utils.dehighlight_utils.Light_Shadow_Remover -- SD-2.x UNet, SD VAE and Euler-ancestral loop on the HIP blocks) runs
+when the caller has its checkpoint; without one the input image is used as it is.  The native pieces run as HIP
 kernels behind the C ABI (r3g.texops: rasterise, interpolate, view weights, fixed-point baking, vertex-propagation
 inpainting); the unwrap is r3g.uvatlas.chart_atlas (axis-projected height-field charts at uniform texel density; the per-face
 atlas of rounds 1-2 remains as `atlas="face"`).  The views that get baked are
+  * the views a `hy3dgen.texgen.utils.multiview_utils.Multiview_Diffusion_Net` generates from the (delighted) image and the
+    normal / position maps this pipeline renders for the six views -- upstream's flow, on the HIP 2.5D UNet -- when the caller has
+    that model's checkpoint, or
   * the views a caller-supplied `multiview_model(image, views) -> list of RGB images` produces, when one is given, or
   * by default ONLY the input image, registered to the front view of the mesh (its alpha silhouette against the mesh
     silhouette); every texel no view saw is filled by colour propagation over the mesh.
@@ -65,6 +69,8 @@ class Hunyuan3DPaintPipeline:
     @property
     def source(self):
         pre = "delighted input; " if self.delight_model is not None else ""
+        if self.multiview_model is not None and getattr(self.multiview_model, "wants_control_images", False):
+            return pre + "multiview diffusion model (normal / position maps of %d views), all views baked" % len(self.views)
         if self.multiview_model is not None:
             return pre + "multiview model supplied by the caller, %d views baked" % len(self.views)
         return pre + "input view only (no multiview diffusion model on this path); unseen texels filled by propagation over the mesh"
@@ -90,6 +96,27 @@ class Hunyuan3DPaintPipeline:
             out = out.convert("RGB")
             out.putalpha(image.getchannel("A").resize(out.size, Image.BILINEAR))
         return out
+
+    def _control_maps(self, v, corner_n, views, size, radius, dev, d_f, d_ct):
+        """normal maps and position maps of the views, as upstream's render_normal_multiview(use_abs_coor=True) /
+        render_position_multiview feed the multiview model: world-space normals as (n + 1) / 2, positions scaled into [0, 1],
+        white where the view sees no surface ([UPSTREAM-RECALLED]: the exact colour conventions are not pinned)"""
+        import torch
+        from PIL import Image
+        from r3g import texops
+        d_v = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev)
+        d_n = torch.from_numpy(np.ascontiguousarray(corner_n, np.float32)).to(dev)
+        nmaps, pmaps = [], []
+        for (elev, azim, _) in views:
+            cam = v @ view_rotation(elev, azim).T
+            clip = torch.from_numpy(ortho_clip(cam, (0.0, 0.0), np.array([radius, radius], np.float32), radius * 2.0)).to(dev)
+            fi, bary = texops.rasterize(clip, d_f, size, size)
+            seen = (fi > 0)[..., None]
+            n_img = torch.where(seen, texops.interpolate(d_n, d_ct, fi, bary) * 0.5 + 0.5, torch.ones((), device=dev))
+            p_img = torch.where(seen, texops.interpolate(d_v, d_f, fi, bary) / (2.0 * radius) + 0.5, torch.ones((), device=dev))
+            for dst, img in ((nmaps, n_img), (pmaps, p_img)):
+                dst.append(Image.fromarray((img.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).cpu().numpy(), "RGB"))
+        return nmaps, pmaps
 
     def _front_image(self, image):
         """RGBA PIL image -> (rgb float32 [R, R, 3] in [0, 1], alpha float32 [R, R], alpha bbox in [0, 1] image coordinates)"""
@@ -140,7 +167,19 @@ class Hunyuan3DPaintPipeline:
         d_f, d_uv, d_uvt = torch.from_numpy(f).to(dev), torch.from_numpy(uv).to(dev), torch.from_numpy(uv_tri).to(dev)
         d_ct = torch.from_numpy(corner_tri).to(dev)
         rgb, alpha, abox = self._front_image(image)
-        if self.multiview_model is not None:
+        if self.multiview_model is not None and getattr(self.multiview_model, "wants_control_images", False):
+            # upstream's call: multiview_model(image_prompt, normal_maps + position_maps, camera_info)
+            from PIL import Image
+            from .utils.multiview_utils import camera_index
+            size = int(getattr(self.multiview_model, "view_size", 512))
+            radius0 = float(np.abs(v).max()) * 1.05 + 1e-6
+            nmaps, pmaps = self._control_maps(v, corner_n, self.views, size, radius0, dev, d_f, d_ct)
+            cams = [camera_index(e, a) for (e, a, _) in self.views]
+            out = self.multiview_model(image, nmaps + pmaps, cams)
+            images = [np.ascontiguousarray(np.asarray(im.convert("RGB").resize((R, R), Image.BILINEAR), np.float32) / 255.0)
+                      for im in out]
+            views = self.views
+        elif self.multiview_model is not None:
             images = [np.ascontiguousarray(np.asarray(im, np.float32)) for im in self.multiview_model(image, self.views)]
             views = self.views
         else:

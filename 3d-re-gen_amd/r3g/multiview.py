@@ -45,3 +45,72 @@ class MultiviewUNet:
         labels = None if camera_info_gen is None else [int(v) + self.max_num_ref_image for v in camera_info_gen]
         return self.gen.forward_mv(x, timestep, self.text_gen, class_labels=labels, flags=2 if self.has_reference else 0,
                                    mva_scale=mva_scale, ref_scale=ref_scale)
+
+
+class MultiviewPipeline:
+    """The sampling loop around the multiview UNet: [UPSTREAM-RECALLED] hy3dgen/texgen/hunyuanpaint/pipeline.py
+    `HunyuanPaintPipeline` as `Multiview_Diffusion_Net` drives it -- the delighted image, the normal maps and the position maps of
+    the views are VAE-encoded (a sample of the latent distribution times the scaling factor), the reference copy of the UNet runs
+    once on the image's latents, then `num_inference_steps` (30) Euler-ancestral steps ("trailing" spacing) on the views' latents,
+    every step one evaluation with the reference attention on and, for guidance_scale > 1, one with it off (upstream's
+    unconditional branch: zero reference latents with ref_scale 0), combined as uncond + g (cond - uncond); the views are decoded
+    one by one.  Latents, conditioning latents and noise stay in HBM as rows for the whole loop."""
+
+    def __init__(self, unet, vae, scaling_factor=0.18215, prediction_type="epsilon"):
+        from . import sched as _sched
+        self.unet, self.vae = unet, vae
+        self.scaling_factor = float(scaling_factor)
+        self.scheduler = _sched.EulerAncestralDiscrete(prediction_type=prediction_type, timestep_spacing="trailing")
+        self.device = vae.device
+
+    def encode(self, images, noise):
+        """images NCHW [n, 3, H, W] in [-1, 1]; noise NCHW [n, z, h, w] (N(0,1)) -> latent_dist.sample() * scaling_factor"""
+        zc = self.vae.latent_channels
+        out = []
+        for i in range(images.shape[0]):
+            mom = self.vae.encode(images[i:i + 1])
+            mean, logvar = mom[:, :zc], mom[:, zc:].clamp(-30.0, 20.0)
+            out.append((mean + torch.exp(0.5 * logvar) * noise[i:i + 1].to(self.device)) * self.scaling_factor)
+        return torch.cat(out, dim=0)
+
+    def __call__(self, ref_images, normal_imgs, position_imgs, camera_info_gen, camera_info_ref=None, num_inference_steps=30,
+                 guidance_scale=2.0, generator=None, noise=None, output="image"):
+        """ref_images [n_ref, 3, H, W], normal_imgs / position_imgs [n, 3, H, W] in [-1, 1] -> images NCHW [n, 3, H, W].
+        noise: dict with "ref" [n_ref, z, h, w], "normal", "position", "latents" [n, z, h, w] and "steps" (one [n, z, h, w] per
+        step); drawn from `generator` in that order when absent"""
+        n, n_ref = normal_imgs.shape[0], ref_images.shape[0]
+        f, zc = self.vae.factor, self.vae.latent_channels
+        H, W = normal_imgs.shape[2:]
+        h, w = H // f, W // f
+        steps = int(num_inference_steps)
+        if noise is None:
+            draw = lambda k: torch.randn((k, zc, h, w), generator=generator, dtype=torch.float32)
+            noise = {"ref": draw(n_ref), "normal": draw(n), "position": draw(n), "latents": draw(n)}
+            noise["steps"] = [draw(n) for _ in range(steps)]
+        dev = self.device
+        ref_latents = self.encode(ref_images, noise["ref"])
+        cond_rows = _unet.to_rows(torch.cat([self.encode(normal_imgs, noise["normal"]),
+                                             self.encode(position_imgs, noise["position"])], dim=1))       # [n h w][2 z]
+        self.unet.reference_pass(ref_latents, camera_info_ref)
+        labels = None if camera_info_gen is None else [int(v) + self.unet.max_num_ref_image for v in camera_info_gen]
+        ctx = self.unet.text_gen[0].to(dev, torch.bfloat16).contiguous()
+        sch = self.scheduler.set_timesteps(steps)
+        x = _unet.to_rows(noise["latents"].to(dev)) * sch.init_noise_sigma
+        step_noise = [_unet.to_rows(e.to(dev)) for e in noise["steps"]]
+        inp = torch.empty((n * h * w, 3 * zc), dtype=torch.float32, device=dev)
+        eps_c = torch.empty((n * h * w, zc), dtype=torch.float32, device=dev)
+        eps_u = torch.empty_like(eps_c)
+        gen = self.unet.gen
+        for i in range(steps):
+            t = float(sch.timesteps[i])
+            sch.model_input(x, cond_rows, i, out=inp)
+            gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=2, out=eps_c)
+            if guidance_scale > 1.0:
+                gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=0, out=eps_u)
+                sch.cfg_combine(eps_u, eps_c, guidance_scale, out=eps_c)
+            sch.step(x, eps_c, step_noise[i], i)
+        if output == "latent":
+            return _unet.from_rows(x, h, w, n)
+        x = x / self.scaling_factor
+        views = [self.vae.decode_rows(x[k * h * w:(k + 1) * h * w].contiguous(), h, w)[:, :self.vae.image_channels] for k in range(n)]
+        return torch.cat([_unet.from_rows(v, H, W) for v in views], dim=0)

@@ -320,13 +320,20 @@ int r3g_aekl_decode(r3g_ctx* ctx, const float* d_latent, int height, int width, 
  * [(height/8)(width/8)][2 latent channels] = (mean | log-variance); the distribution's mode is the mean */
 int r3g_aekl_encode(r3g_ctx* ctx, const float* d_image, int height, int width, float* d_moments, void* stream);
 
-/* ---- sampling loop of upstream's delighting model (StableDiffusionInstructPix2PixPipeline with an
- * EulerAncestralDiscreteScheduler, [UPSTREAM-RECALLED] hy3dgen/texgen/utils/dehighlight_utils.py) around r3g_unet_forward:
- * the two elementwise steps diffusers runs between UNet evaluations.  Stateless (no context). */
-/* d_out f32 [pixels][2 channels] = (d_latent[p] / sqrt(sigma^2 + 1) | d_image_latent[p]):
- * scheduler.scale_model_input(latents, t) and torch.cat([latents, image_latents], dim=1) on rows */
+/* ---- sampling loops of upstream's diffusion pipelines (the delighting StableDiffusionInstructPix2PixPipeline and the
+ * multiview pipeline, both with an EulerAncestralDiscreteScheduler; [UPSTREAM-RECALLED] hy3dgen/texgen/utils/dehighlight_utils.py,
+ * hy3dgen/texgen/hunyuanpaint/pipeline.py) around r3g_unet_forward / r3g_unet_forward_mv: the elementwise steps diffusers runs
+ * between UNet evaluations.  Stateless (no context). */
+/* d_out f32 [pixels][channels + cond_channels] = (d_latent[p] / sqrt(sigma^2 + 1) | d_cond[p]):
+ * scheduler.scale_model_input(latents, t) and torch.cat([latents, conditioning latents], dim=1) on rows (InstructPix2Pix: the image
+ * latents; the multiview pipeline: the normal- and position-map latents of the view) */
+int r3g_sched_model_input(const float* d_latent, int channels, const float* d_cond, int cond_channels, int64_t pixels, float sigma,
+                          float* d_out, void* stream);
+/* the InstructPix2Pix case: cond_channels = channels */
 int r3g_sched_pix2pix_input(const float* d_latent, const float* d_image_latent, int channels, int64_t pixels, float sigma,
                             float* d_out, void* stream);
+/* classifier-free guidance: d_out[i] = d_uncond[i] + guidance_scale (d_cond[i] - d_uncond[i]) */
+int r3g_sched_cfg_combine(const float* d_uncond, const float* d_cond, int64_t n, float guidance_scale, float* d_out, void* stream);
 /* EulerAncestralDiscreteScheduler.step in place on d_sample f32 [n]: prediction_type 0 epsilon | 1 v_prediction;
  * sigma_up^2 = sigma_to^2 (sigma_from^2 - sigma_to^2) / sigma_from^2, sigma_down^2 = sigma_to^2 - sigma_up^2,
  * sample += (sample - x0) / sigma_from * (sigma_down - sigma_from) + d_noise * sigma_up */
