@@ -75,12 +75,36 @@ class Hunyuan3DPaintPipeline:
             return pre + "multiview model supplied by the caller, %d views baked" % len(self.views)
         return pre + "input view only (no multiview diffusion model on this path); unseen texels filled by propagation over the mesh"
 
+    DELIGHT_SUBFOLDER = "hunyuan3d-delight-v2-0"      # upstream's from_pretrained: <model_path>/<these two folders>
+    MULTIVIEW_SUBFOLDER = "hunyuan3d-paint-v2-0"
+
     @classmethod
     def from_pretrained(cls, model_path=None, subfolder=None, **kwargs):
-        """upstream loads the delight and multiview diffusion checkpoints here; this path has neither (see module doc)"""
+        """upstream builds Hunyuan3DTexGenConfig(<model_path>/hunyuan3d-delight-v2-0, <model_path>/hunyuan3d-paint-v2-0) and loads
+        the two diffusion models from there.  Here: a folder that exists is loaded (and a folder that cannot be loaded is an
+        error, not a silent fallback); a model passed explicitly wins; with neither, the pipeline runs without that model and
+        `source` says so"""
         allowed = ("texture_size", "render_size", "multiview_model", "views", "cos_threshold", "depth_edge", "power",
                    "dilate_iters", "device", "atlas", "delight_model")
-        return cls(**{k: v for k, v in kwargs.items() if k in allowed})
+        kw = {k: v for k, v in kwargs.items() if k in allowed}
+        if model_path and os.path.isdir(str(model_path)):
+            dev = kw.get("device") or 0
+            if not isinstance(dev, int):          # "cuda:1" / torch.device -> the index the r3g classes take
+                dev = int(str(dev).rsplit(":", 1)[1]) if ":" in str(dev) else 0
+
+            class _Cfg:
+                device = dev
+            d = os.path.join(str(model_path), cls.DELIGHT_SUBFOLDER)
+            m = os.path.join(str(model_path), cls.MULTIVIEW_SUBFOLDER)
+            if kw.get("delight_model") is None and os.path.isdir(d):
+                from .utils.dehighlight_utils import Light_Shadow_Remover
+                _Cfg.light_remover_ckpt_path = d
+                kw["delight_model"] = Light_Shadow_Remover(_Cfg)
+            if kw.get("multiview_model") is None and os.path.isdir(m):
+                from .utils.multiview_utils import Multiview_Diffusion_Net
+                _Cfg.multiview_ckpt_path = m
+                kw["multiview_model"] = Multiview_Diffusion_Net(_Cfg)
+        return cls(**kw)
 
     # -- helpers -----------------------------------------------------------------------------------------------------
     def _device(self):

@@ -18,6 +18,48 @@ import os
 import numpy as np
 
 
+def read_weights(folder):
+    """the state dict of a diffusers component folder: diffusion_pytorch_model.safetensors, or the older .bin (a torch pickle of
+    tensors only)"""
+    st = os.path.join(folder, "diffusion_pytorch_model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    pt = os.path.join(folder, "diffusion_pytorch_model.bin")
+    if os.path.exists(pt):
+        import torch
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    raise FileNotFoundError("no diffusion_pytorch_model.safetensors / .bin in %s" % folder)
+
+
+def read_json(path, default=None):
+    if not os.path.exists(path):
+        if default is None:
+            raise FileNotFoundError(path)
+        return default
+    with open(path) as f:
+        return json.load(f)
+
+
+def unet_config_from_diffusers(uc, ctx_tokens):
+    """diffusers unet/config.json -> the keys this path uses; refuses layouts it does not run"""
+    ch = tuple(uc["block_out_channels"])
+    heads = uc.get("attention_head_dim", 8)
+    heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(ch)
+    if any(c // h_ != 64 for c, h_ in zip(ch, heads)):
+        raise ValueError("this path runs head dim 64 (the SD 2.x layout: attention_head_dim = heads per block)")
+    if not uc.get("use_linear_projection", False):
+        raise ValueError("this path needs use_linear_projection (SD 2.x)")
+    return dict(block_out_channels=ch, layers_per_block=uc.get("layers_per_block", 2), cross_attention_dim=uc["cross_attention_dim"],
+                ctx_tokens=int(ctx_tokens), temb_dim=4 * ch[0], groups=uc.get("norm_num_groups", 32))
+
+
+def vae_config_from_diffusers(vc):
+    return dict(block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
+                latent_channels=vc.get("latent_channels", 4), image_channels=vc.get("in_channels", 3),
+                groups=vc.get("norm_num_groups", 32))
+
+
 def erode3(alpha):
     """cv2.erode(alpha, np.ones((3, 3), np.uint8), iterations=1): minimum over the 3 x 3 neighbourhood; cv2's default border
     for erosion does not lower the result (the border counts as +infinity)"""
@@ -70,41 +112,26 @@ class Light_Shadow_Remover:
 
     @staticmethod
     def load(path, device=0):
-        """a diffusers InstructPix2Pix checkpoint directory: unet/ and vae/ (config.json + diffusion_pytorch_model.safetensors)
-        and `prompt_embeds_empty.safetensors` (key "prompt_embeds": the text encoder's last hidden state for the prompt "",
-        computed once with the checkpoint's own tokenizer / text_encoder -- INTEGRATION.md)"""
+        """a diffusers InstructPix2Pix checkpoint directory: unet/ and vae/ (config.json + diffusion_pytorch_model.safetensors
+        or .bin), scheduler/scheduler_config.json (prediction_type) and `prompt_embeds_empty.safetensors` (key "prompt_embeds":
+        the text encoder's last hidden state for the prompt "", computed once with the checkpoint's own tokenizer / text_encoder
+        -- INTEGRATION.md)"""
         from safetensors.torch import load_file
         from r3g.delight import InstructPix2Pix
-
-        def cfg(sub):
-            with open(os.path.join(path, sub, "config.json")) as f:
-                return json.load(f)
-        uc, vc = cfg("unet"), cfg("vae")
-        ch = tuple(uc["block_out_channels"])
-        heads = uc.get("attention_head_dim", 8)
-        heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(ch)
-        if any(c // h_ != 64 for c, h_ in zip(ch, heads)):
-            raise ValueError("this path runs head dim 64 (the SD 2.x layout: attention_head_dim = heads per block)")
-        if not uc.get("use_linear_projection", False):
-            raise ValueError("this path needs use_linear_projection (SD 2.x)")
-        sched_cfg = {}
-        sp = os.path.join(path, "scheduler", "scheduler_config.json")
-        if os.path.exists(sp):
-            with open(sp) as f:
-                sched_cfg = json.load(f)
-        prompt = load_file(os.path.join(path, "prompt_embeds_empty.safetensors"))["prompt_embeds"]
-        unet_config = dict(block_out_channels=ch, layers_per_block=uc.get("layers_per_block", 2),
-                           cross_attention_dim=uc["cross_attention_dim"], ctx_tokens=int(prompt.shape[-2]),
-                           temb_dim=4 * ch[0], groups=uc.get("norm_num_groups", 32))
-        vae_config = dict(block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
-                          latent_channels=vc.get("latent_channels", 4), image_channels=vc.get("in_channels", 3),
-                          groups=vc.get("norm_num_groups", 32))
-        model = InstructPix2Pix(load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")),
-                                load_file(os.path.join(path, "vae", "diffusion_pytorch_model.safetensors")), unet_config,
-                                vae_config, image_size=Light_Shadow_Remover.size,
+        pe = os.path.join(path, "prompt_embeds_empty.safetensors")
+        if not os.path.exists(pe):
+            raise FileNotFoundError("%s is missing: the CLIP text encoder is not on this path, the embedding of the empty prompt "
+                                    "has to be computed once where diffusers is installed (INTEGRATION.md)" % pe)
+        prompt = load_file(pe)["prompt_embeds"]
+        prompt = prompt.reshape(1, prompt.shape[-2], prompt.shape[-1])
+        vc = read_json(os.path.join(path, "vae", "config.json"))
+        unet_config = unet_config_from_diffusers(read_json(os.path.join(path, "unet", "config.json")), prompt.shape[1])
+        sched_cfg = read_json(os.path.join(path, "scheduler", "scheduler_config.json"), default={})
+        model = InstructPix2Pix(read_weights(os.path.join(path, "unet")), read_weights(os.path.join(path, "vae")), unet_config,
+                                vae_config_from_diffusers(vc), image_size=Light_Shadow_Remover.size,
                                 scaling_factor=vc.get("scaling_factor", 0.18215),
                                 prediction_type=sched_cfg.get("prediction_type", "epsilon"), device=device)
-        return model, prompt.reshape(1, prompt.shape[-2], prompt.shape[-1])
+        return model, prompt
 
     def prepare(self, image):
         """PIL image -> (rgb uint8 [S, S, 3] fed to the model, rgb_target float [S, S, 3], alpha float [S, S, 1])"""

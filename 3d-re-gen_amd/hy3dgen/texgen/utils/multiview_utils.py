@@ -29,11 +29,41 @@ class Multiview_Diffusion_Net:
     wants_control_images = True          # Hunyuan3DPaintPipeline renders normal / position maps for this model
 
     def __init__(self, config=None, pipeline=None):
-        """pipeline: an r3g.multiview.MultiviewPipeline.  (upstream: built from config.multiview_ckpt_path; a loader for that
-        checkpoint layout belongs here once a checkpoint exists to check it against)"""
+        """pipeline: an r3g.multiview.MultiviewPipeline; or a config that carries `multiview_ckpt_path` (upstream's attribute):
+        the checkpoint directory is read here (load)"""
         if pipeline is None:
-            raise ValueError("Multiview_Diffusion_Net needs an r3g.multiview.MultiviewPipeline (no checkpoint loader on this path yet)")
+            path = getattr(config, "multiview_ckpt_path", None) if config is not None else None
+            if not path:
+                raise ValueError("Multiview_Diffusion_Net needs a pipeline or config.multiview_ckpt_path")
+            pipeline = self.load(path, device=getattr(config, "device", 0))
         self.pipeline = pipeline
+
+    @classmethod
+    def load(cls, path, device=0, n_views_max=6):
+        """upstream's multiview checkpoint directory ([UPSTREAM-RECALLED] layout: a diffusers pipeline folder whose unet/ holds
+        the UNet2p5DConditionModel state dict -- "unet.*", "unet_dual.*" -- next to the wrapped UNet's config.json, a vae/ and a
+        scheduler/): -> r3g.multiview.MultiviewPipeline sized for `n_views_max` views of view_size x view_size"""
+        import os
+        from r3g.multiview import MultiviewPipeline, MultiviewUNet
+        from r3g.unet import AutoencoderKLBlocks
+        from .dehighlight_utils import read_json, read_weights, unet_config_from_diffusers, vae_config_from_diffusers
+        sd = read_weights(os.path.join(path, "unet"))
+        text = [v for k, v in sd.items() if k.endswith("learned_text_clip_gen")]
+        if not text:
+            raise ValueError("%s/unet holds no 'unet.learned_text_clip_gen': not a UNet2p5DConditionModel state dict" % path)
+        unet_config = unet_config_from_diffusers(read_json(os.path.join(path, "unet", "config.json")), text[0].shape[-2])
+        vc = read_json(os.path.join(path, "vae", "config.json"))
+        vcfg = vae_config_from_diffusers(vc)
+        factor = 2 ** (len(vcfg["block_out_channels"]) - 1)
+        lat = cls.view_size // factor
+        vae = AutoencoderKLBlocks(read_weights(os.path.join(path, "vae")), block_out_channels=vcfg["block_out_channels"],
+                                  layers_per_block=vcfg["layers_per_block"], latent_channels=vcfg["latent_channels"],
+                                  image_channels=vcfg["image_channels"], groups=vcfg["groups"],
+                                  max_image_hw=cls.view_size * cls.view_size, device=device)
+        unet = MultiviewUNet(sd, unet_config, n_views_max=n_views_max, n_ref_max=1, latent_hw=lat * lat, device=device)
+        sched_cfg = read_json(os.path.join(path, "scheduler", "scheduler_config.json"), default={})
+        return MultiviewPipeline(unet, vae, scaling_factor=vc.get("scaling_factor", 0.18215),
+                                 prediction_type=sched_cfg.get("prediction_type", "epsilon"))
 
     @staticmethod
     def _tensor(images, size):

@@ -133,3 +133,49 @@ def test_upstream_flow_through_the_paint_pipeline(pair):
     assert out.texture.shape == (256, 256, 3) and out.metadata["texture_source"].startswith("delighted input; multiview diffusion model")
     st = pipe.last_stats
     assert st["texels_painted_by_views"] > 0.8 * st["texels_covered"]        # six views see (nearly) the whole sphere
+
+
+def test_both_models_load_from_checkpoint_folders_and_match_their_oracles(tmp_path, monkeypatch):
+    """Hunyuan3DPaintPipeline.from_pretrained(<folder with hunyuan3d-delight-v2-0/ and hunyuan3d-paint-v2-0/>): the state dicts
+    travel file -> loader -> re-layout -> HBM, and what runs there matches the oracle built from the same tensors"""
+    import torch
+    from PIL import Image
+    import tex_ckpt_support as CK
+    import tex_support as ts
+    from hy3dgen.texgen import Hunyuan3DPaintPipeline
+    from hy3dgen.texgen.utils.dehighlight_utils import Light_Shadow_Remover
+    from hy3dgen.texgen.utils.multiview_utils import Multiview_Diffusion_Net
+    from oracle import mvpaint_torch as MP, pix2pix_torch as P
+    from r3g.mesh import Mesh
+    dl, mv = CK.write_checkpoints(str(tmp_path))
+    monkeypatch.setattr(Light_Shadow_Remover, "size", 64)
+    monkeypatch.setattr(Light_Shadow_Remover, "steps", 2)
+    monkeypatch.setattr(Multiview_Diffusion_Net, "view_size", 64)
+    monkeypatch.setattr(Multiview_Diffusion_Net, "steps", 2)
+    pipe = Hunyuan3DPaintPipeline.from_pretrained(str(tmp_path), texture_size=256, render_size=128)
+    assert pipe.source.startswith("delighted input; multiview diffusion model")
+    # the delighting model as loaded
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    lat = torch.randn(1, 4, 16, 16, generator=g)
+    noise = [torch.randn(1, 4, 16, 16, generator=g) for _ in range(3)]
+    want = P.instruct_pix2pix(dl["unet"], dl["vae"], dl["prompt_embeds"], img, 3, lat, noise)
+    got = pipe.delight_model.model(img, pipe.delight_model.prompt_embeds, num_inference_steps=3, latents=lat, step_noise=noise).cpu()
+    e = rel_l2(got, want)
+    report("texckpt.delight model loaded from its folder, 3 steps", e, 3e-2)
+    assert e < 3e-2
+    # the multiview model as loaded (its UNet from a torch pickle)
+    ref, nm, ps, nz = _inputs(6, 1, 64, 3, 7)
+    want = MP.multiview_paint(mv["unet"], mv["vae"], ref, nm, ps, list(range(6)), [0], 3, nz)
+    got = pipe.multiview_model.pipeline(ref, nm, ps, list(range(6)), [0], num_inference_steps=3, noise=nz).cpu()
+    e = rel_l2(got, want)
+    report("texckpt.multiview model loaded from its folder, 3 guided steps", e, 5e-2)
+    assert e < 5e-2
+    # and the stage's call
+    v, f = ts.icosphere(3)
+    rgba = np.zeros((96, 96, 4), np.uint8)
+    rgba[..., :3] = 200
+    yy, xx = np.mgrid[0:96, 0:96]
+    rgba[..., 3] = np.where((xx - 47.5) ** 2 + (yy - 47.5) ** 2 < 40 ** 2, 255, 0)
+    out = pipe(Mesh(v, f), image=Image.fromarray(rgba, "RGBA"))
+    assert out.texture.shape == (256, 256, 3) and pipe.last_stats["texels_painted_by_views"] > 0.8 * pipe.last_stats["texels_covered"]

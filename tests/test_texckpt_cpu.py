@@ -1,0 +1,103 @@
+"""Loading the two texture models from checkpoint directories, CPU side: the folder layouts are parsed into the configurations and
+state dicts the HIP classes take (those classes are replaced by recorders here -- they need an MI355X), and from_pretrained picks
+the two sub-folders up the way upstream's does."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "3d-re-gen_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import tex_ckpt_support as CK  # noqa: E402
+
+
+class _Rec:
+    calls = []
+
+    def __init__(self, *a, **k):
+        type(self).calls.append((type(self).__name__, a, k))
+        self.device = "cpu"
+        self.factor, self.latent_channels, self.image_channels = 4, 4, 3
+        self.max_num_ref_image = 5
+
+
+@pytest.fixture()
+def patched(monkeypatch, tmp_path):
+    import r3g.delight
+    import r3g.multiview
+    import r3g.unet
+    _Rec.calls = []
+    for mod, name in ((r3g.delight, "InstructPix2Pix"), (r3g.multiview, "MultiviewUNet"), (r3g.unet, "AutoencoderKLBlocks")):
+        monkeypatch.setattr(mod, name, type(name, (_Rec,), {}))
+    pieces = CK.write_checkpoints(str(tmp_path))
+    return str(tmp_path), pieces
+
+
+def test_delight_folder_is_parsed(patched):
+    from hy3dgen.texgen.utils.dehighlight_utils import Light_Shadow_Remover
+    root, (dl, _) = patched
+
+    class Cfg:
+        light_remover_ckpt_path = os.path.join(root, "hunyuan3d-delight-v2-0")
+        device = 0
+    r = Light_Shadow_Remover(Cfg)
+    name, a, k = _Rec.calls[-1]
+    assert name == "InstructPix2Pix"
+    usd, vsd, ucfg, vcfg = a
+    assert ucfg == dict(block_out_channels=(64, 128), layers_per_block=2, cross_attention_dim=128, ctx_tokens=13, temb_dim=256, groups=32)
+    assert vcfg == dict(block_out_channels=(64, 64, 128), layers_per_block=1, latent_channels=4, image_channels=3, groups=32)
+    assert usd["conv_in.weight"].shape[1] == 8 and "decoder.conv_out.bias" in vsd
+    assert k["image_size"] == 512 and k["prediction_type"] == "epsilon" and abs(k["scaling_factor"] - 0.18215) < 1e-9
+    assert torch.equal(r.prompt_embeds, dl["prompt_embeds"])
+    os.remove(os.path.join(Cfg.light_remover_ckpt_path, "prompt_embeds_empty.safetensors"))
+    with pytest.raises(FileNotFoundError, match="empty prompt"):
+        Light_Shadow_Remover(Cfg)
+
+
+def test_multiview_folder_is_parsed_from_a_torch_pickle(patched):
+    from hy3dgen.texgen.utils.multiview_utils import Multiview_Diffusion_Net
+    root, _ = patched
+
+    class Cfg:
+        multiview_ckpt_path = os.path.join(root, "hunyuan3d-paint-v2-0")
+        device = 0
+    net = Multiview_Diffusion_Net(Cfg)
+    names = [c[0] for c in _Rec.calls]
+    assert names[-2:] == ["AutoencoderKLBlocks", "MultiviewUNet"]
+    _, a, k = _Rec.calls[-1]
+    sd, ucfg = a
+    assert "unet.learned_text_clip_gen" in sd and "unet_dual.conv_in.weight" in sd and ucfg["ctx_tokens"] == 13
+    assert k["n_views_max"] == 6 and k["latent_hw"] == (512 // 4) ** 2           # the small VAE has three levels: factor 4
+    assert net.pipeline.scheduler.timestep_spacing == "trailing" and net.pipeline.scaling_factor == 0.18215
+    os.remove(os.path.join(Cfg.multiview_ckpt_path, "unet", "diffusion_pytorch_model.bin"))
+    with pytest.raises(FileNotFoundError):
+        Multiview_Diffusion_Net(Cfg)
+
+
+def test_from_pretrained_picks_up_the_two_subfolders(patched):
+    from hy3dgen.texgen import Hunyuan3DPaintPipeline
+    from hy3dgen.texgen.utils.dehighlight_utils import Light_Shadow_Remover
+    from hy3dgen.texgen.utils.multiview_utils import Multiview_Diffusion_Net
+    root, _ = patched
+    p = Hunyuan3DPaintPipeline.from_pretrained(root, device="cuda:0")
+    assert isinstance(p.delight_model, Light_Shadow_Remover) and isinstance(p.multiview_model, Multiview_Diffusion_Net)
+    assert p.source.startswith("delighted input; multiview diffusion model")
+    mine = object()
+    q = Hunyuan3DPaintPipeline.from_pretrained(root, multiview_model=mine)      # an explicit model wins
+    assert q.multiview_model is mine and isinstance(q.delight_model, Light_Shadow_Remover)
+    plain = Hunyuan3DPaintPipeline.from_pretrained("synthetic:mini")           # no such folder: the stage's default
+    assert plain.delight_model is None and plain.multiview_model is None and plain.source.startswith("input view only")
+
+
+def test_unsupported_unet_layouts_are_refused():
+    from hy3dgen.texgen.utils.dehighlight_utils import unet_config_from_diffusers
+    base = {"block_out_channels": [320, 640], "attention_head_dim": [5, 10], "use_linear_projection": True, "cross_attention_dim": 1024}
+    assert unet_config_from_diffusers(base, 77)["temb_dim"] == 1280
+    with pytest.raises(ValueError, match="head dim 64"):
+        unet_config_from_diffusers(dict(base, attention_head_dim=8), 77)       # SD 1.x: 8 heads of 40 / 80
+    with pytest.raises(ValueError, match="use_linear_projection"):
+        unet_config_from_diffusers(dict(base, use_linear_projection=False), 77)
