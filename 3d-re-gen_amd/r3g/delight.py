@@ -35,6 +35,11 @@ class InstructPix2Pix:
         self.scaling_factor = float(scaling_factor)
         self.device = self.vae.device
 
+    def close(self):
+        """give the two contexts' HBM back"""
+        self.unet.close()
+        self.vae.close()
+
     def __call__(self, image, prompt_embeds, num_inference_steps=50, generator=None, latents=None, step_noise=None,
                  output="image"):
         """image NCHW [1, 3, H, W] in [-1, 1]; prompt_embeds [1, tokens, ctx_dim].  Noise: `latents` [1, z, h, w] and

@@ -31,6 +31,11 @@ class MultiviewUNet:
         self.text_ref = extra["learned_text_clip_ref"].detach().reshape(1, -1, c["cross_attention_dim"])
         self.has_reference = False
 
+    def close(self):
+        """give both contexts' HBM back (the generator first: it points into the reference copy's kept states)"""
+        self.gen.close()
+        self.ref.close()
+
     def reference_pass(self, ref_latents, camera_info_ref=None):
         """ref_latents NCHW [n_ref, 4, h, w] of ONE object: the reference copy runs once at timestep 0 and keeps every
         transformer's normalised hidden states; the generator is pointed at them"""

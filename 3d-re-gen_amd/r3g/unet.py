@@ -99,7 +99,34 @@ def from_rows(r, h, w, n=1):
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
 
-class UnetBlocks:
+class _OwnsContext:
+    """the wrapper owns one library context (its arena and weight table): close() -- or garbage collection -- gives the HBM back.
+    A generator that reads another instance's kept states (set_condition) must not outlive that instance's close()."""
+    ctx = None
+
+    def close(self):
+        ctx, self.ctx = self.ctx, None
+        if ctx is None:
+            return
+        try:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()          # nothing in flight reads the arena or the weights any more
+                self.L.r3g_destroy(ctx)
+        except Exception:          # interpreter shutdown (modules already torn down): the process's memory goes with it
+            pass
+        self._w = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class UnetBlocks(_OwnsContext):
     def __init__(self, state_dict, max_hw, max_channels, temb_dim, ctx_dim, ctx_tokens, groups=32, resnet_eps=1e-5, device=0,
                  block_out_channels=(), layers_per_block=2, in_channels=4, out_channels=4):
         """block_out_channels: the level structure for forward() (empty: building blocks only); max_channels must then cover
@@ -283,7 +310,7 @@ def prepare_aekl_weights(sd, device):
     return out
 
 
-class AutoencoderKLBlocks:
+class AutoencoderKLBlocks(_OwnsContext):
     """diffusers AutoencoderKL (SD family) on the HIP blocks: encode(image) -> moments, decode(latent) -> image"""
 
     def __init__(self, state_dict, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
