@@ -5,8 +5,9 @@ with a camera embedding added to the time embedding and 12 input channels (laten
 Two library contexts: the generator and the plain 4-channel reference copy (`unet_dual`); the reference pass keeps norm1's output
 of every transformer in HBM and the generator reads it from there (no copy, no host round trip).
 
-This is the model only (one evaluation = r3g_unet_forward_mv over all views); upstream's sampling pipeline around it (VAE
-encoding of the rendered normal / position maps, classifier-free guidance, scheduler) is not on this path yet."""
+MultiviewUNet is the model (one evaluation = r3g_unet_forward_mv over all views); MultiviewPipeline is upstream's sampling loop
+around it (VAE encoding of the image and of the rendered normal / position maps, classifier-free guidance, Euler-ancestral steps,
+VAE decoding of the views)."""
 import torch
 
 from . import unet as _unet
