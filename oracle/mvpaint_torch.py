@@ -45,4 +45,6 @@ def multiview_paint(unet, vae, ref_images, normal_imgs, position_imgs, camera_in
         x = P.euler_ancestral_step(x, eps, noise["steps"][i], sig[i], sig[i + 1])
     if output == "latent":
         return x
+    if output == "both":           # (final latents, decoded views) of ONE run of the loop
+        return x, vae.decode(x / scaling_factor)
     return vae.decode(x / scaling_factor)

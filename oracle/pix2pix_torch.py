@@ -54,4 +54,6 @@ def instruct_pix2pix(unet, vae, prompt_embeds, image, num_inference_steps, laten
         x = euler_ancestral_step(x, eps, step_noise[i], sig[i], sig[i + 1], prediction_type)
     if output == "latent":
         return x
+    if output == "both":           # (final latents, decoded image) of ONE run of the loop
+        return x, vae.decode(x / scaling_factor)
     return vae.decode(x / scaling_factor)

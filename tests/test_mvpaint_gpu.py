@@ -73,8 +73,7 @@ def test_sampling_loop_small(pair, n, size, steps, g):
     from oracle import mvpaint_torch as MP
     ref, nm, ps, noise = _inputs(n, 1, size, steps, 50 + steps)
     cams = list(range(n))
-    want_z = MP.multiview_paint(pair.unet, pair.vae, ref, nm, ps, cams, [0], steps, noise, guidance_scale=g, output="latent")
-    want = MP.multiview_paint(pair.unet, pair.vae, ref, nm, ps, cams, [0], steps, noise, guidance_scale=g)
+    want_z, want = MP.multiview_paint(pair.unet, pair.vae, ref, nm, ps, cams, [0], steps, noise, guidance_scale=g, output="both")
     got_z = pair.pipe(ref, nm, ps, cams, [0], num_inference_steps=steps, guidance_scale=g, noise=noise, output="latent").cpu()
     got = pair.pipe(ref, nm, ps, cams, [0], num_inference_steps=steps, guidance_scale=g, noise=noise).cpu()
     assert got.shape == want.shape and torch.isfinite(got).all()

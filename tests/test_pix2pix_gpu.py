@@ -75,8 +75,7 @@ def test_instruct_pix2pix_loop_small(pair, steps, size):
     h = size // 4
     lat = torch.randn(1, 4, h, h, generator=g)
     noise = [torch.randn(1, 4, h, h, generator=g) for _ in range(steps)]
-    ref_z = P.instruct_pix2pix(pair.unet, pair.vae, pair.pe, img, steps, lat, noise, output="latent")
-    ref = P.instruct_pix2pix(pair.unet, pair.vae, pair.pe, img, steps, lat, noise)
+    ref_z, ref = P.instruct_pix2pix(pair.unet, pair.vae, pair.pe, img, steps, lat, noise, output="both")
     got_z = pair.gpu(img, pair.pe, num_inference_steps=steps, latents=lat, step_noise=noise, output="latent").cpu()
     got = pair.gpu(img, pair.pe, num_inference_steps=steps, latents=lat, step_noise=noise).cpu()
     assert torch.isfinite(got).all() and got.shape == ref.shape
