@@ -2,7 +2,9 @@
 """Time of the texture stage at upstream's sizes with both diffusion models on the HIP blocks (random weights of the real
 architectures: SD-2.1 UNet with 8 input channels + SD VAE for delighting, the 2.5D UNet + its 4-channel reference copy + SD VAE for
 the six views; 50 / 30 steps at 512 x 512; 2048^2 texture, 1024^2 bake renders, a 20 480-face sphere).  Prints one JSON line.
-    python tools/texture_stage_time.py > gpurun_out/r03_texture_stage_time.json"""
+Lives under tests/ because it takes the weights' SHAPES from the oracle's module definitions (random tensors of the real
+architectures); nothing of the oracle is executed or timed.
+    python tests/tex_stage_time.py > gpurun_out/r03_texture_stage_time.json"""
 import json
 import os
 import sys
@@ -11,7 +13,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "3d-re-gen_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
