@@ -245,6 +245,11 @@ def main():
         torch.cuda.synchronize()
 
     run(crops[:a.warmup])
+    if dist is not None:
+        # the mesh return's point-to-point channels (RCCL opens one per pair of ranks on first use) are opened by a one-vertex
+        # gather before the clock starts, like every other first-use cost of the warm-up
+        rdist.gather_meshes([(rank, torch.zeros((1, 3), dtype=torch.float32), torch.zeros((1, 3), dtype=torch.int32))], dst=0,
+                            to_host=False)
     barrier()
     t0 = time.perf_counter()
     meshes = run(crops[a.warmup:a.warmup + a.steps])       # EXACTLY a.steps objects
