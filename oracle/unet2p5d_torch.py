@@ -21,7 +21,6 @@ State-dict names follow that structure: "unet.<...>.transformer_blocks.0.transfo
 "unet.<...>.transformer_blocks.0.attn_multiview.to_q.weight", "unet.class_embedding.weight", "unet.learned_text_clip_gen",
 "unet_dual.<plain names>".
 """
-import copy
 import math
 
 import torch
