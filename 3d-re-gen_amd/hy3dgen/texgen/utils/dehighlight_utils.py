@@ -41,6 +41,16 @@ def read_json(path, default=None):
         return json.load(f)
 
 
+# what the HIP UNet implements of diffusers' UNet2DConditionModel configuration space: a config.json that says otherwise is
+# refused (a silently different architecture would produce plausible-looking garbage)
+_UNET_FIXED = {
+    "act_fn": "silu", "flip_sin_to_cos": True, "freq_shift": 0, "resnet_time_scale_shift": "default", "mid_block_scale_factor": 1,
+    "class_embed_type": None, "addition_embed_type": None, "time_embedding_type": "positional", "dual_cross_attention": False,
+    "only_cross_attention": False, "conv_in_kernel": 3, "conv_out_kernel": 3, "encoder_hid_dim": None,
+    "mid_block_type": "UNetMidBlock2DCrossAttn", "transformer_layers_per_block": 1, "norm_eps": 1e-5, "downsample_padding": 1,
+}
+
+
 def unet_config_from_diffusers(uc, ctx_tokens):
     """diffusers unet/config.json -> the keys this path uses; refuses layouts it does not run"""
     ch = tuple(uc["block_out_channels"])
@@ -50,11 +60,26 @@ def unet_config_from_diffusers(uc, ctx_tokens):
         raise ValueError("this path runs head dim 64 (the SD 2.x layout: attention_head_dim = heads per block)")
     if not uc.get("use_linear_projection", False):
         raise ValueError("this path needs use_linear_projection (SD 2.x)")
+    n = len(ch)
+    want_down = ["CrossAttnDownBlock2D"] * (n - 1) + ["DownBlock2D"]
+    want_up = ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * (n - 1)
+    if list(uc.get("down_block_types", want_down)) != want_down or list(uc.get("up_block_types", want_up)) != want_up:
+        raise ValueError("this path runs the SD layout of blocks (%s / %s)" % (want_down, want_up))
+    bad = {k: uc[k] for k, v in _UNET_FIXED.items() if k in uc and uc[k] != v and not (v is None and uc[k] in (None, "None"))}
+    if bad:
+        raise ValueError("unet/config.json asks for what this path does not implement: %s" % bad)
     return dict(block_out_channels=ch, layers_per_block=uc.get("layers_per_block", 2), cross_attention_dim=uc["cross_attention_dim"],
                 ctx_tokens=int(ctx_tokens), temb_dim=4 * ch[0], groups=uc.get("norm_num_groups", 32))
 
 
 def vae_config_from_diffusers(vc):
+    """diffusers vae/config.json (AutoencoderKL) -> the keys this path uses; refuses what the HIP VAE does not implement"""
+    n = len(vc["block_out_channels"])
+    if list(vc.get("down_block_types", ["DownEncoderBlock2D"] * n)) != ["DownEncoderBlock2D"] * n or \
+            list(vc.get("up_block_types", ["UpDecoderBlock2D"] * n)) != ["UpDecoderBlock2D"] * n:
+        raise ValueError("this path runs AutoencoderKL's DownEncoderBlock2D / UpDecoderBlock2D layout")
+    if vc.get("act_fn", "silu") != "silu" or not vc.get("mid_block_add_attention", True) or vc.get("out_channels", 3) != vc.get("in_channels", 3):
+        raise ValueError("vae/config.json asks for what this path does not implement (act_fn silu, mid-block attention, in = out channels)")
     return dict(block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
                 latent_channels=vc.get("latent_channels", 4), image_channels=vc.get("in_channels", 3),
                 groups=vc.get("norm_num_groups", 32))

@@ -101,3 +101,16 @@ def test_unsupported_unet_layouts_are_refused():
         unet_config_from_diffusers(dict(base, attention_head_dim=8), 77)       # SD 1.x: 8 heads of 40 / 80
     with pytest.raises(ValueError, match="use_linear_projection"):
         unet_config_from_diffusers(dict(base, use_linear_projection=False), 77)
+    with pytest.raises(ValueError, match="act_fn"):
+        unet_config_from_diffusers(dict(base, act_fn="gelu"), 77)
+    with pytest.raises(ValueError, match="layout of blocks"):
+        unet_config_from_diffusers(dict(base, down_block_types=["DownBlock2D", "DownBlock2D"]), 77)
+    # the real SD-2.1 unet/config.json passes
+    sd21 = {"act_fn": "silu", "attention_head_dim": [5, 10, 20, 20], "block_out_channels": [320, 640, 1280, 1280], "center_input_sample": False,
+            "cross_attention_dim": 1024, "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "downsample_padding": 1,
+            "dual_cross_attention": False, "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "layers_per_block": 2,
+            "mid_block_scale_factor": 1, "norm_eps": 1e-05, "norm_num_groups": 32, "num_class_embeds": None, "only_cross_attention": False,
+            "out_channels": 4, "sample_size": 96, "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3, "upcast_attention": True,
+            "use_linear_projection": True}
+    assert unet_config_from_diffusers(sd21, 77) == dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                                                        cross_attention_dim=1024, ctx_tokens=77, temb_dim=1280, groups=32)
