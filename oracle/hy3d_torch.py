@@ -494,10 +494,66 @@ def _resize_u8(arr, w, h, resample):
     return np.asarray(Image.fromarray(arr).resize((w, h), resample))
 
 
+def _area_axis(a, n_out):
+    """shrink axis 0 of a float64 array by the pixel-area relation, written through the running integral of the signal: the mean
+    over [i s, (i + 1) s) is (F((i + 1) s) - F(i s)) / s with F piecewise linear between the prefix sums (an independent
+    formulation of what the product builds as gathered, weighted taps)"""
+    n_in = a.shape[0]
+    s = n_in / n_out
+    F = np.concatenate([np.zeros((1,) + a.shape[1:]), np.cumsum(a, axis=0)], axis=0)           # F[k] = sum of the first k pixels
+
+    def at(t):
+        t = np.minimum(t, n_in)
+        k = np.minimum(np.floor(t).astype(np.int64), n_in - 1)
+        frac = (t - k).reshape((-1,) + (1,) * (a.ndim - 1))
+        return F[k] + frac * a[k]
+    lo = np.arange(n_out) * s
+    hi = np.minimum(lo + s, n_in)
+    return (at(hi) - at(lo)) / (hi - lo).reshape((-1,) + (1,) * (a.ndim - 1))
+
+
+def _grow_axis(a, n_out):
+    """OpenCV INTER_AREA along axis 0 when it grows ([RECALLED] imgproc/resize.cpp): two taps, coefficients fx = frac((d + 1) -
+    (sx + 1) n_out / n_in) (0 when negative), as 11-bit integers; returns the integer sums at scale 2^11"""
+    n_in = a.shape[0]
+    out = np.empty((n_out,) + a.shape[1:], np.int64)
+    for d in range(n_out):
+        sx = int(np.floor(d * (n_in / n_out)))
+        fx = np.float32((d + 1) - (sx + 1) * (n_out / n_in))
+        fx = np.float32(0) if fx <= 0 else np.float32(fx - np.floor(fx))
+        if sx >= n_in - 1:
+            sx, fx = n_in - 1, np.float32(0)
+        c1 = int(np.rint(fx * np.float32(2048)))
+        c0 = int(np.rint((np.float32(1) - fx) * np.float32(2048)))
+        out[d] = a[sx] * c0 + a[min(sx + 1, n_in - 1)] * c1
+    return out
+
+
+def resize_area(arr, w, h):
+    """cv2.INTER_AREA restated for uint8 [H][W][C] (cv2 is absent here; the product restates it independently as weighted taps)"""
+    H, W = arr.shape[:2]
+    if w <= W and h <= H:
+        out = _area_axis(arr.astype(np.float64), h)
+        out = _area_axis(out.transpose(1, 0, 2), w).transpose(1, 0, 2)
+        return np.rint(out).clip(0, 255).astype(np.uint8)
+    a = arr.astype(np.int64)
+    rows = _grow_axis(a.transpose(1, 0, 2), w).transpose(1, 0, 2)          # horizontal pass first, scale 2^11
+    H0 = rows.shape[0]
+    out = np.empty((h,) + rows.shape[1:], np.int64)
+    for d in range(h):
+        sy = int(np.floor(d * (H0 / h)))
+        fy = np.float32((d + 1) - (sy + 1) * (h / H0))
+        fy = np.float32(0) if fy <= 0 else np.float32(fy - np.floor(fy))
+        if sy >= H0 - 1:
+            sy, fy = H0 - 1, np.float32(0)
+        b1 = int(np.rint(fy * np.float32(2048)))
+        b0 = int(np.rint((np.float32(1) - fy) * np.float32(2048)))
+        out[d] = (((rows[sy] >> 4) * b0) >> 16) + (((rows[min(sy + 1, H0 - 1)] >> 4) * b1) >> 16)
+    return ((out + 2) >> 2).clip(0, 255).astype(np.uint8)
+
+
 def recenter(image, border_ratio):
-    """ImageProcessorV2.recenter (cv2.INTER_AREA replaced by PIL BOX: cv2 is absent in this image; the
-    same restated function is used on the product side, so both sides see identical pixels)."""
-    from PIL import Image
+    """ImageProcessorV2.recenter; cv2.INTER_AREA restated (resize_area above; rounds 1-2 used PIL BOX)."""
     mask = image[..., 3]
     H, W, C = image.shape
     size = max(H, W)
@@ -513,7 +569,7 @@ def recenter(image, border_ratio):
     h2, w2 = int(h * scale), int(w * scale)
     x2 = (size - h2) // 2
     y2 = (size - w2) // 2
-    result[x2:x2 + h2, y2:y2 + w2] = _resize_u8(image[x_min:x_max, y_min:y_max], w2, h2, Image.BOX)
+    result[x2:x2 + h2, y2:y2 + w2] = resize_area(image[x_min:x_max, y_min:y_max], w2, h2)
     bg = np.ones((size, size, 3), dtype=np.uint8) * 255
     m = result[..., 3:].astype(np.float32) / 255
     rgb = result[..., :3] * m + bg * (1 - m)
