@@ -65,6 +65,9 @@ def resize_area_u8(arr, w, h):
     from scipy.sparse import csr_matrix
     arr = np.ascontiguousarray(arr)
     H, W, C = arr.shape
+    if H == 2 * h and W == 2 * w:               # OpenCV's fast path for exactly 2 x 2: integer mean, halves rounded UP
+        a = arr.astype(np.int32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
     if w <= W and h <= H:                       # shrinking (or equal): the area relation, float32 accumulation, round half to even
         out = _apply(_area_operator(H, h), _area_operator(W, w), arr.astype(np.float32))
         return np.rint(out).clip(0, 255).astype(np.uint8)

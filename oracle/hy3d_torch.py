@@ -532,6 +532,9 @@ def _grow_axis(a, n_out):
 def resize_area(arr, w, h):
     """cv2.INTER_AREA restated for uint8 [H][W][C] (cv2 is absent here; the product restates it independently as weighted taps)"""
     H, W = arr.shape[:2]
+    if H == 2 * h and W == 2 * w:               # resizeAreaFast, 2 x 2: (a + b + c + d + 2) >> 2
+        q = arr.astype(np.int64).reshape(h, 2, w, 2, -1).sum(axis=(1, 3))
+        return ((q + 2) >> 2).astype(np.uint8)
     if w <= W and h <= H:
         out = _area_axis(arr.astype(np.float64), h)
         out = _area_axis(out.transpose(1, 0, 2), w).transpose(1, 0, 2)

@@ -49,6 +49,15 @@ def test_shrinking_is_the_pixel_area_relation(shape, size):
         assert np.array_equal(got, arr)
 
 
+def test_exact_halving_rounds_halves_up_like_opencvs_fast_path():
+    arr = np.zeros((4, 4, 1), np.uint8)
+    arr[0, 0] = 2                                   # block sums 2, 0, 0, 0 -> means 0.5, 0, 0, 0
+    arr[2:, 2:] = [[[1], [2]], [[3], [4]]]          # 10 / 4 = 2.5
+    got = P.resize_area_u8(arr, 2, 2)[..., 0]
+    assert got.tolist() == [[1, 0], [0, 3]]         # half-even would give 0 and 2
+    assert np.array_equal(H.resize_area(arr, 2, 2)[..., 0], got)
+
+
 def test_integer_ratio_is_the_block_mean():
     rng = np.random.default_rng(5)
     arr = rng.integers(0, 256, (64, 48, 4), dtype=np.uint8)
