@@ -108,4 +108,4 @@ def test_what_the_box_filter_was_off_by_and_the_cost():
     for _ in range(5):
         P.resize_area_u8(crop, 416, 435)
     ms = 1000 * (time.perf_counter() - t0) / 5
-    assert ms < 60, ms                                                         # host time per object, inside the bench's timed region
+    assert ms < 500, ms      # a guard against an accidental dense-matrix version (640 ms), not a benchmark: ~10-30 ms here
