@@ -146,7 +146,7 @@ class Light_Shadow_Remover:
         pe = os.path.join(path, "prompt_embeds_empty.safetensors")
         if not os.path.exists(pe):
             raise FileNotFoundError("%s is missing: the CLIP text encoder is not on this path, the embedding of the empty prompt "
-                                    "has to be computed once where diffusers is installed (INTEGRATION.md)" % pe)
+                                    "is computed once with `python tools/make_prompt_embeds.py %s` (INTEGRATION.md)" % (pe, path))
         prompt = load_file(pe)["prompt_embeds"]
         prompt = prompt.reshape(1, prompt.shape[-2], prompt.shape[-1])
         vc = read_json(os.path.join(path, "vae", "config.json"))

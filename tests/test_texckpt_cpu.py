@@ -114,3 +114,35 @@ def test_unsupported_unet_layouts_are_refused():
             "use_linear_projection": True}
     assert unet_config_from_diffusers(sd21, 77) == dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                                                         cross_attention_dim=1024, ctx_tokens=77, temb_dim=1280, groups=32)
+
+
+def test_prompt_embedding_tool_writes_what_the_loader_reads(tmp_path):
+    """tools/make_prompt_embeds.py on a tiny random CLIP text encoder saved the way diffusers pipelines store one"""
+    import importlib.util
+    import json
+    from safetensors.torch import load_file
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "tok_src"))
+    vocab = {"<|startoftext|>": 0, "<|endoftext|>": 1, "!</w>": 2, "a</w>": 3}
+    with open(os.path.join(d, "tok_src", "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(d, "tok_src", "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n")
+    tok = CLIPTokenizer(os.path.join(d, "tok_src", "vocab.json"), os.path.join(d, "tok_src", "merges.txt"), pad_token="!", model_max_length=77)
+    tok.save_pretrained(os.path.join(d, "tokenizer"))
+    cfg = CLIPTextConfig(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=77, bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    torch.manual_seed(0)
+    enc = CLIPTextModel(cfg).eval()
+    enc.save_pretrained(os.path.join(d, "text_encoder"))
+    spec = importlib.util.spec_from_file_location("make_prompt_embeds", os.path.join(ROOT, "tools", "make_prompt_embeds.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.main([d]) == 0
+    got = load_file(os.path.join(d, "prompt_embeds_empty.safetensors"))["prompt_embeds"]
+    ids = tok("", padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    assert ids[0, 0] == 0 and ids[0, 1] == 1 and ids.shape == (1, 77)          # <start>, <end>, padding
+    with torch.no_grad():
+        want = enc(ids)[0]
+    assert got.shape == (1, 77, 64) and torch.allclose(got, want, atol=1e-6)
