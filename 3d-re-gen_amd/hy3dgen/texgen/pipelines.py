@@ -111,6 +111,31 @@ class Hunyuan3DPaintPipeline:
         import torch
         return torch.device(self.device or ("cuda:%d" % torch.cuda.current_device()))
 
+    @staticmethod
+    def recenter_image(image, border_ratio=0.2):
+        """[UPSTREAM-RECALLED] Hunyuan3DPaintPipeline.recenter_image, the first thing upstream's __call__ does with the image prompt:
+        crop an RGBA image to its alpha bounding box and paste it, with a border of `border_ratio` of the crop on every side, in the
+        middle of a transparent square; RGB / L images pass through"""
+        from PIL import Image
+        if image.mode == "RGB":
+            return image
+        if image.mode == "L":
+            return image.convert("RGB")
+        if image.mode != "RGBA":
+            image = image.convert("RGBA")
+        alpha = np.asarray(image)[:, :, 3]
+        rows, cols = np.nonzero(alpha > 0)
+        if len(rows) == 0:
+            raise ValueError("Image is fully transparent")
+        cropped = image.crop((int(cols.min()), int(rows.min()), int(cols.max()) + 1, int(rows.max()) + 1))
+        width, height = cropped.size
+        bw, bh = int(width * border_ratio), int(height * border_ratio)
+        new_w, new_h = width + 2 * bw, height + 2 * bh
+        side = max(new_w, new_h)
+        out = Image.new("RGBA", (side, side), (255, 255, 255, 0))
+        out.paste(cropped, ((side - new_w) // 2 + bw, (side - new_h) // 2 + bh))
+        return out
+
     def _delight(self, image):
         """upstream: image_prompt = self.models['delight_model'](image_prompt).  The delighted picture comes back as RGB over
         white at the model's size; the alpha it is registered by stays the input's."""
@@ -164,6 +189,9 @@ class Hunyuan3DPaintPipeline:
             raise ValueError("Hunyuan3DPaintPipeline needs the object's image")
         if mesh.is_empty:
             return mesh
+        upstream_flow = self.delight_model is not None or getattr(self.multiview_model, "wants_control_images", False)
+        if upstream_flow:
+            image = self.recenter_image(image)
         if self.delight_model is not None:
             image = self._delight(image)
         dev = self._device()

@@ -85,3 +85,20 @@ def test_multiview_diffusion_net_bookkeeping():
         net(ctl[0], ctl, [0, 1])                          # one camera index per view
     with pytest.raises(ValueError):
         MU.Multiview_Diffusion_Net()
+
+
+def test_recenter_image_of_the_paint_pipeline():
+    from PIL import Image
+    from hy3dgen.texgen import Hunyuan3DPaintPipeline as PP
+    arr = np.zeros((100, 120, 4), np.uint8)
+    arr[20:60, 30:110] = (10, 200, 30, 255)                       # a 40 x 80 object
+    out = PP.recenter_image(Image.fromarray(arr, "RGBA"))
+    assert out.mode == "RGBA" and out.size == (112, 112)           # 80 + 2 x 16 wide, 40 + 2 x 8 high -> square of 112
+    o = np.asarray(out)
+    ys, xs = np.nonzero(o[..., 3])
+    assert (xs.min(), xs.max() + 1, ys.min(), ys.max() + 1) == (16, 96, 36, 76)      # centred, border 16 left and right
+    assert tuple(o[50, 50]) == (10, 200, 30, 255) and tuple(o[0, 0]) == (255, 255, 255, 0)
+    rgb = Image.new("RGB", (8, 8))
+    assert PP.recenter_image(rgb) is rgb and PP.recenter_image(Image.new("L", (8, 8))).mode == "RGB"
+    with pytest.raises(ValueError):
+        PP.recenter_image(Image.fromarray(np.zeros((8, 8, 4), np.uint8), "RGBA"))
