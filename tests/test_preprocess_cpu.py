@@ -109,3 +109,21 @@ def test_what_the_box_filter_was_off_by_and_the_cost():
         P.resize_area_u8(crop, 416, 435)
     ms = 1000 * (time.perf_counter() - t0) / 5
     assert ms < 500, ms      # a guard against an accidental dense-matrix version (640 ms), not a benchmark: ~10-30 ms here
+
+
+def test_area_relation_properties_over_random_shapes():
+    """whatever the ratio: constants survive, values stay inside the input's range, and the image mean is preserved to rounding
+    when shrinking (every source pixel's total weight is out/in on each axis)"""
+    rng = np.random.default_rng(11)
+    for _ in range(25):
+        H0, W0 = int(rng.integers(2, 60)), int(rng.integers(2, 60))
+        h, w = int(rng.integers(1, H0 + 1)), int(rng.integers(1, W0 + 1))
+        arr = rng.integers(0, 256, (H0, W0, 2), dtype=np.uint8)
+        out = P.resize_area_u8(arr, w, h)
+        assert out.shape == (h, w, 2) and out.min() >= arr.min() and out.max() <= arr.max()
+        assert abs(out.astype(np.float64).mean() - arr.astype(np.float64).mean()) <= 0.5 + 127.5 * (1.0 / max(h * w, 1)) ** 0.5
+        flat = np.full((H0, W0, 2), int(rng.integers(0, 256)), np.uint8)
+        assert np.array_equal(P.resize_area_u8(flat, w, h), np.full((h, w, 2), flat[0, 0, 0], np.uint8))
+        grow_h, grow_w = H0 + int(rng.integers(1, 20)), W0 + int(rng.integers(1, 20))
+        big = P.resize_area_u8(arr, grow_w, grow_h)
+        assert big.shape == (grow_h, grow_w, 2) and np.array_equal(big, H.resize_area(arr, grow_w, grow_h))
