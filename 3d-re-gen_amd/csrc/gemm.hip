@@ -25,44 +25,14 @@
 #include <type_traits>
 #include <utility>
 
+#include "gemm_common.h"
 #include "kernels.h"
 #include "prof.h"
 
 namespace r3g {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
 constexpr int BK = 64;
-
-__device__ __forceinline__ float gelu_tanh(float x) {
-    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as x sigmoid(2u) =
-    // x / (1 + 2^(x (c1 + c3 x^2))): 4 plain VALU + v_exp_f32 + v_rcp_f32 (round 3; the textbook form took 10 + 2 and lost
-    // relative accuracy in the negative tail to the cancellation in 1 + tanh).  Saturates cleanly: 2^(+inf) -> rcp -> 0.
-    constexpr float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-    constexpr float c3 = c1 * 0.044715f;
-    const float z = x * fmaf(x * x, c3, c1);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
-}
-
-// exact-form GELU, x Phi(x), with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step):
-// h = erfc(|x| / sqrt 2) / 2 = t (b1 + t (b2 + ...)) 2^(-x^2 log2(e) / 2), Phi = x >= 0 ? 1 - h : h (no cancellation in the tail)
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.7071067811865476f, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
-    const float h = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f)))) * e;
-    return x * (x >= 0.f ? 1.0f - h : h);
-}
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-// v_cvt_pk_bf16_f32 (round to nearest even)
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    return *reinterpret_cast<const uint32_t*>(&h);
-}
 
 // one operand tile: ROWS rows x 64 k, in pieces of 1 KiB (8 rows), spread over NW waves
 template <bool GLDS, int NW, int ROWS>
@@ -347,10 +317,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (p.bias) bj = *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : p.N - 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const f32x4 v = acc[j][i] + bj;
+                const f32x4 v = gelu_erf4(acc[j][i] + bj) * inv;
                 int w = 0;
-                w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_erf(v[0]) * inv, gelu_erf(v[1]) * inv, w, false);
-                w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_erf(v[2]) * inv, gelu_erf(v[3]) * inv, w, true);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
                 const int r = i * 16 + (lane & 15), m = mrow + i * 16;
                 if (wide) *reinterpret_cast<uint32_t*>(lds_wave + r * 64 + ((j ^ (r & 3)) << 4) + ((lane >> 4) << 2)) = (uint32_t)w;
                 else if (n < p.N && m < p.M) *reinterpret_cast<uint32_t*>(C8 + (int64_t)m * p.ldc + n) = (uint32_t)w;
@@ -567,13 +537,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     const int i = ip + ii;
                     const int n = ncol + j * 16, m = mrow + i * 16;
                     f32x4 v = acc[j][i] + biasv[j];
-                    if (EPI == EPI_BF16_GELU_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                    } else if (EPI == EPI_BF16_GELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
+                    if (EPI == EPI_BF16_GELU_TANH) v = gelu_tanh4(v);
+                    else if (EPI == EPI_BF16_GELU_ERF) v = gelu_erf4(v);
                     if (EPI != EPI_F32 && wide) {
                         uint2 pk;
                         pk.x = pack_bf16(v[0], v[1]);
@@ -1722,10 +1687,18 @@ int g_gemm_persistent_resid = 0;   // experiment switch (r3g_set_option "gemm_pe
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
+int g_gemm_stream = 0;   // gemm4.hip: 0 off | 1 where a compute unit gets at least two tiles | 2 wherever the kernel applies
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStream_t s) {
-    int waves = g_gemm_waves;
+    // bf16 outputs with a short K: the 4-wave stream kernel (gemm_waves == 14 forces it where it applies)
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) {
+        if (g_gemm_waves == 14 || (g_gemm_waves == 0 && g_gemm_stream > 0)) {
+            const hipError_t e = launch_gemm4(p, p2, g_num_cu, g_gemm_waves == 14 || g_gemm_stream > 1, s);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
+    int waves = g_gemm_waves == 14 ? 0 : g_gemm_waves;
     const int batch = p.batch;
     if (waves == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
@@ -1805,8 +1778,9 @@ void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
+void gemm_set_stream(int mode) { g_gemm_stream = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void gemm_set_config(int waves) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 14 || waves == 16 || waves == 32) g_gemm_waves = waves;
 }
 
 static bool gemm_args_ok(const GemmArgs& p) {

@@ -1248,6 +1248,8 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_persistent")) gemm_set_persistent(value != 0);
     else if (!strcmp(name, "gemm_persistent_resid")) gemm_set_persistent_resid(value);
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
+    else if (!strcmp(name, "gemm_stream")) gemm_set_stream(value);
+    else if (!strcmp(name, "gemm4_ablate")) gemm4_set_ablate(value);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);

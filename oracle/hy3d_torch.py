@@ -623,9 +623,11 @@ class ShapePipeline(nn.Module):
         return torch.cat([cond, torch.zeros_like(cond)], dim=0)   # [cond, uncond]
 
     @torch.no_grad()
-    def sample(self, cond2, latents, num_inference_steps, guidance_scale, trace=None):
+    def sample(self, cond2, latents, num_inference_steps, guidance_scale, trace=None, first_step=0, callback=None):
+        """first_step / callback(i, latents): resume point and per-step hook of long runs (tools/make_cfg1_golden.py);
+        the arithmetic of a step does not depend on them"""
         sig = flow_sigmas(num_inference_steps, self.cfg["sched"]["shift"])
-        for i in range(num_inference_steps):
+        for i in range(first_step, num_inference_steps):
             t = torch.full((2,), float(sig[i]), dtype=latents.dtype)   # timesteps/num_train_timesteps == sigma
             v = self.model(torch.cat([latents] * 2), t, cond2)
             v_c, v_u = v.chunk(2)
@@ -633,6 +635,8 @@ class ShapePipeline(nn.Module):
             latents = latents + float(sig[i + 1] - sig[i]) * v
             if trace is not None:
                 trace.append(latents.clone())
+            if callback is not None:
+                callback(i, latents)
         return latents
 
     @torch.no_grad()
