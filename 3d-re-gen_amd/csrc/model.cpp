@@ -58,8 +58,13 @@ constexpr float kGeoHiddenScale = 1.0f / 16.0f;   // static scale of the fp8 MLP
 static bool g_geo_resid_bf16 = true;   // geo decoder block: 16-bit residual stream (the reference's is fp16)
 static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context as one weighted token
 static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached intermediate results (Model::GeoCache) are tied to it
+static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
+// r3g_flow_sample runs steps [g_flow_first_step, g_flow_last_step) of its schedule (options "flow_first_step" / "flow_last_step";
+// default: all of them).  Consecutive segments of one schedule, each continuing on the previous one's latents, are the same
+// launches as the whole schedule in one call: tests read the latents after 10, 20, ... of 50 steps this way.
+static int g_flow_first_step = 0, g_flow_last_step = 1 << 30;
 
 struct Model {
     r3g_model_config c{};
@@ -810,17 +815,25 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
     // (no allocation for a call that contains no canonical pass, e.g. a test's 3 000-point slice of the grid)
     const bool has_canon = start % m.qc == 0 && count >= std::min<int64_t>(m.qc, total - start);
     if (use_cache && !gq.x0 && !gq.refused && has_canon) {
-        const size_t need = (size_t)passes_all * m.qc * W * 2 * 2;
+        // The cache lives outside torch's allocator and stays until the model goes (or "geo_q_cache_release"): it takes at most
+        // its budget (option "geo_q_cache_gb"; default 30 % of the device's memory: 86 GB of 288, the whole 257^3 grid needs
+        // 68) and never the last 16 GB that are free now.  A grid that does not fit (380^3: 227 GB, 513^3: 557 GB) gets a
+        // PREFIX of its passes cached; the passes behind it are recomputed per object, as before.
+        const size_t per_pass = (size_t)m.qc * W * 2 * 2;
         size_t free_b = 0, total_b = 0;
         hipError_t e = hipMemGetInfo(&free_b, &total_b);
-        if (e != hipSuccess || free_b < need + ((size_t)16 << 30) || hipMalloc((void**)&gq.x0, need) != hipSuccess) {
+        size_t budget = g_geo_q_cache_bytes >= 0 ? (size_t)g_geo_q_cache_bytes : (size_t)(0.30 * (double)total_b);
+        if (e == hipSuccess && free_b > ((size_t)16 << 30)) budget = std::min(budget, free_b - ((size_t)16 << 30));
+        else budget = 0;
+        const int64_t n_cached = std::min<int64_t>(passes_all, (int64_t)(budget / per_pass));
+        if (n_cached < 1 || hipMalloc((void**)&gq.x0, (size_t)n_cached * per_pass) != hipSuccess) {
             (void)hipGetLastError();
             gq.x0 = nullptr;
-            gq.refused = true;            // e.g. 513^3: 557 GB -- every pass is recomputed, as before
+            gq.refused = true;            // every pass is recomputed, as before
         } else {
-            gq.Q = gq.x0 + (int64_t)passes_all * m.qc * W;
-            gq.passes = passes_all;
-            gq.built.assign((size_t)passes_all, 0);
+            gq.Q = gq.x0 + n_cached * (int64_t)m.qc * W;
+            gq.passes = n_cached;
+            gq.built.assign((size_t)n_cached, 0);
         }
     }
     use_cache = use_cache && gq.x0 != nullptr;
@@ -835,7 +848,7 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         // multiple of the pass size and covers the pass completely (sub-range queries are computed the old way)
         const int64_t p0 = start + off;
         const int64_t pidx = p0 / m.qc;
-        const bool canon = use_cache && p0 % m.qc == 0 && n == (int)std::min<int64_t>(m.qc, total - p0);
+        const bool canon = use_cache && pidx < gq.passes && p0 % m.qc == 0 && n == (int)std::min<int64_t>(m.qc, total - p0);
         const bool hit = canon && gq.built[(size_t)pidx];
         uint16_t* x0 = canon ? gq.x0 + pidx * (int64_t)m.qc * W : reinterpret_cast<uint16_t*>(m.f32a);
         uint16_t* Qp = canon ? gq.Q + pidx * (int64_t)m.qc * W : m.Q;
@@ -1096,7 +1109,7 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
         for (int o = 0; o < n_objects; ++o) {
             float* lat = d_latents + o * n;
             const uint16_t* cond2 = d_cond2 + 2 * o * cond_elems;
-            for (int i = 0; i < steps; ++i) {
+            for (int i = std::max(0, g_flow_first_step); i < std::min(steps, g_flow_last_step); ++i) {
                 const float ds = sig[i + 1] - sig[i];
                 if (ds == 0.f && g_skip_zero_step) continue;
                 R3G_TRY(hipMemcpyAsync(x2, lat, n * 4, hipMemcpyDeviceToDevice, s));
@@ -1119,7 +1132,7 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
             R3G_TRY(hipMemcpyAsync(dst + cond_elems, cond2 + cond_elems, (size_t)c.dit_context_dim * 2, hipMemcpyDeviceToDevice, s));
         }
         float* lat = d_latents + o0 * n;
-        for (int i = 0; i < steps; ++i) {
+        for (int i = std::max(0, g_flow_first_step); i < std::min(steps, g_flow_last_step); ++i) {
             // the final step of upstream's schedule has d_sigma = 0: its update is x += 0 * v, so the evaluation is skipped
             // (bit-identical; r3g_set_option("skip_zero_step", 0) evaluates it as upstream does)
             const float ds = sig[i + 1] - sig[i];
@@ -1128,6 +1141,21 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
             for (int o = 0; o < NB; ++o) R3G_TRY(cfg_euler_launch(lat + o * n, d.v2 + 2 * o * n, n, guidance_scale, ds, s));
         }
     }
+    return R3G_OK;
+}
+
+int r3g_model_trim(r3g_ctx* ctx) {
+    NEED_MODEL("r3g_model_trim");
+    Model::GeoCache& gq = m->gq;
+    if (gq.x0) {
+        R3G_TRY(hipDeviceSynchronize());
+        (void)hipFree(gq.x0);
+        gq.x0 = nullptr;
+        gq.Q = nullptr;
+        gq.passes = 0;
+        gq.built.clear();
+    }
+    gq.refused = false;
     return R3G_OK;
 }
 
@@ -1235,6 +1263,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "cfg_dedup")) g_cfg_dedup = value != 0;
     else if (!strcmp(name, "skip_zero_step")) g_skip_zero_step = value != 0;
     else if (!strcmp(name, "geo_q_cache")) g_geo_q_cache = value != 0;
+    else if (!strcmp(name, "geo_q_cache_gb")) g_geo_q_cache_bytes = value < 0 ? -1 : (long long)value << 30;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
@@ -1249,6 +1278,8 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_persistent_resid")) gemm_set_persistent_resid(value);
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
     else if (!strcmp(name, "gemm_stream")) gemm_set_stream(value);
+    else if (!strcmp(name, "flow_first_step")) g_flow_first_step = value;
+    else if (!strcmp(name, "flow_last_step")) g_flow_last_step = value < 0 ? (1 << 30) : value;
     else if (!strcmp(name, "gemm4_ablate")) gemm4_set_ablate(value);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);

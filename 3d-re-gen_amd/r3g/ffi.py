@@ -50,6 +50,7 @@ SYMBOLS = {
     "r3g_model_create": (_I, [_P, _P]),
     "r3g_model_set_tensor": (_I, [_P, ctypes.c_char_p, _P, _I, ctypes.c_int64, ctypes.c_int64]),
     "r3g_model_set_scalar": (_I, [_P, ctypes.c_char_p, ctypes.c_float]),
+    "r3g_model_trim": (_I, [_P]),
     "r3g_cond_encode": (_I, [_P, _P, _P, _P]),
     "r3g_dit_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "r3g_dit_stream": (_I, [_P, _P, _I, _P]),

@@ -127,6 +127,12 @@ class ShapeModel:
             ShapeModel._current[self.device.index] = self
         self._have_z = False
 
+    def trim(self):
+        """give the query-side cache of the geo decoder back to the device (r3g_model_trim); it is rebuilt on the next grid query"""
+        if self.private_ctx or ShapeModel._current.get(self.device.index) is self:
+            with torch.cuda.device(self.device):
+                _l.check(self.L.r3g_model_trim(self.ctx))
+
     def _activate(self):
         if not self.private_ctx and ShapeModel._current.get(self.device.index) is not self:
             self._install()

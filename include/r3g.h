@@ -179,6 +179,12 @@ int r3g_model_create(r3g_ctx* ctx, const r3g_model_config* cfg);
  * (Replaces load_state_dict of the safetensors checkpoint.) */
 int r3g_model_set_tensor(r3g_ctx* ctx, const char* name, const void* d_ptr, int dtype, int64_t rows, int64_t cols);
 int r3g_model_set_scalar(r3g_ctx* ctx, const char* name, float value);
+/* Give back the device memory the model holds beyond its weights and its arena: the query-side cache of the geo decoder
+ * (r3g_grid_query keeps the object-independent half of every grid pass resident, up to the budget of option
+ * "geo_q_cache_gb", default 30 % of the device's memory).  The next r3g_grid_query builds it again.  A stage that
+ * is about to start another large consumer on the same GPU (texture models, a second process) calls this first.
+ * Synchronises the device.  No counterpart upstream (the reference recomputes the query side per chunk). */
+int r3g_model_trim(r3g_ctx* ctx);
 
 /* conditioner forward: d_image f32 [3][S][S] already resized/cropped/normalised (ImageEncoder.transform);
  * d_cond_out bf16 [S/14*S/14+1][cond_hidden] = Dinov2Model(...).last_hidden_state (CLS first). */
@@ -386,7 +392,14 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
- * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0).  None of them changes a
+ * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "geo_q_cache_gb" (the
+ * budget of geo_q_cache in GiB; < 0, the default: 30 % of the device's memory; a grid that needs more gets a prefix of its passes
+ * cached), "gemm_stream" (0 default | 1 | 2: bf16-output GEMMs with K >= 1024 on the 4-wave stream kernel of csrc/gemm4.hip where a
+ * compute unit gets two tiles or more | wherever it applies; also gemm_waves = 14; bit-identical, measured slower than the
+ * persistent phased kernel -- profiles/r04_gemm_stream.md), "gemm4_ablate" (timing-only masks for that kernel, results are
+ * garbage), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive
+ * segments continuing on each other's latents are the same launches as one call -- how tests read the latents after 10, 20, ...
+ * of 50 steps).  None of them changes a
  * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation
  * (different rounding points inside the softmax). */
 int r3g_set_option(const char* name, int value);
