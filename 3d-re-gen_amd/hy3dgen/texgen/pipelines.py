@@ -81,29 +81,58 @@ class Hunyuan3DPaintPipeline:
     @classmethod
     def from_pretrained(cls, model_path=None, subfolder=None, **kwargs):
         """upstream builds Hunyuan3DTexGenConfig(<model_path>/hunyuan3d-delight-v2-0, <model_path>/hunyuan3d-paint-v2-0) and loads
-        the two diffusion models from there.  Here: a folder that exists is loaded (and a folder that cannot be loaded is an
-        error, not a silent fallback); a model passed explicitly wins; with neither, the pipeline runs without that model and
-        `source` says so"""
+        the two diffusion models from there.  Here: a folder that exists is loaded (a folder that cannot be loaded is an error;
+        with strict=False it is recorded in `load_problems` and the pipeline runs without that model -- the stage does that, loudly,
+        so that a snapshot whose texture folders this loader cannot read still yields meshes); a model passed explicitly wins;
+        with neither, the pipeline runs without that model and `source` says so.  The models live on `device` (default: the
+        process's current device -- a rank's own GPU)"""
         allowed = ("texture_size", "render_size", "multiview_model", "views", "cos_threshold", "depth_edge", "power",
                    "dilate_iters", "device", "atlas", "delight_model")
         kw = {k: v for k, v in kwargs.items() if k in allowed}
+        strict = bool(kwargs.get("strict", True))
         if model_path and os.path.isdir(str(model_path)):
-            dev = kw.get("device") or 0
+            dev = kw.get("device")
+            if dev is None:                       # the process's current device (a rank's own GPU), as _device() chooses it
+                import torch
+                dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
             if not isinstance(dev, int):          # "cuda:1" / torch.device -> the index the r3g classes take
-                dev = int(str(dev).rsplit(":", 1)[1]) if ":" in str(dev) else 0
+                if ":" in str(dev):
+                    dev = int(str(dev).rsplit(":", 1)[1])
+                else:
+                    import torch
+                    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            kw["device"] = "cuda:%d" % dev
 
             class _Cfg:
                 device = dev
             d = os.path.join(str(model_path), cls.DELIGHT_SUBFOLDER)
             m = os.path.join(str(model_path), cls.MULTIVIEW_SUBFOLDER)
-            if kw.get("delight_model") is None and os.path.isdir(d):
+            problems = []
+
+            def load(what, folder, make):
+                if kw.get(what) is not None or not os.path.isdir(folder):
+                    return
+                try:
+                    kw[what] = make()
+                except Exception as e:      # noqa: BLE001 -- a checkpoint folder this loader cannot read
+                    if strict:
+                        raise
+                    problems.append("%s: %s: %s" % (os.path.basename(folder), type(e).__name__, e))
+
+            def make_delight():
                 from .utils.dehighlight_utils import Light_Shadow_Remover
                 _Cfg.light_remover_ckpt_path = d
-                kw["delight_model"] = Light_Shadow_Remover(_Cfg)
-            if kw.get("multiview_model") is None and os.path.isdir(m):
+                return Light_Shadow_Remover(_Cfg)
+
+            def make_multiview():
                 from .utils.multiview_utils import Multiview_Diffusion_Net
                 _Cfg.multiview_ckpt_path = m
-                kw["multiview_model"] = Multiview_Diffusion_Net(_Cfg)
+                return Multiview_Diffusion_Net(_Cfg)
+            load("delight_model", d, make_delight)
+            load("multiview_model", m, make_multiview)
+            pipe = cls(**kw)
+            pipe.load_problems = problems      # strict=False: what could not be loaded (the stage prints it and goes on)
+            return pipe
         return cls(**kw)
 
     # -- helpers -----------------------------------------------------------------------------------------------------

@@ -73,6 +73,12 @@ class Multiview_Diffusion_Net:
         for im in images:
             if not isinstance(im, Image.Image):
                 im = Image.fromarray((np.clip(np.asarray(im, np.float32), 0, 1) * 255 + 0.5).astype(np.uint8))
+            if im.mode in ("RGBA", "LA"):
+                # an image prompt that still carries alpha (no delighting model in front: that step composites): over white,
+                # as Light_Shadow_Remover does -- whatever RGB sits under alpha = 0 must not become the reference image
+                rgba = np.asarray(im.convert("RGBA"), np.float32) / 255.0
+                a = rgba[:, :, 3:4]
+                im = Image.fromarray(((rgba[:, :, :3] * a + (1.0 - a)) * 255.0 + 0.5).astype(np.uint8), "RGB")
             im = im.convert("RGB").resize((size, size))
             arrs.append(np.asarray(im, np.float32) / 255.0)
         return torch.from_numpy(np.stack(arrs)).permute(0, 3, 1, 2) * 2.0 - 1.0

@@ -222,36 +222,47 @@ def gather_meshes(local, dst=0, to_host=True):
             return (v, f) if tex is None else (v, f, uv, tex)
         return (v.cpu().numpy(), f.cpu().numpy()) if tex is None else (v.cpu().numpy(), f.cpu().numpy(), uv.cpu().numpy(),
                                                                       tex.cpu().numpy())
+    # The transfers: ONE batch of point-to-point operations per rank (torch.distributed.batch_isend_irecv = one RCCL group).
+    # Rank `dst` posts the receives of every peer's meshes at once, each peer posts all of its sends at once: the peers'
+    # meshes travel over their own xGMI links at the same time, and nobody waits for a slower rank's turn (round 3 drained
+    # the ranks one after the other with blocking recv calls -- 8 ranks x 20 MB serialised on the slowest one).  The operations
+    # of one pair of ranks match in posting order: both sides walk the sender's list in the same order.
     out = {}
+    ops, landing = [], []
     if rank == dst:
         for i, v, f, uv, tex in mine:
             out[i] = pack(v, f, uv, tex)
         for r in range(world):
             if r == dst:
                 continue
-            for (i, nv, nf, t0, t1, t2) in meta[r]:       # the sender walks the same list in the same order
+            for (i, nv, nf, t0, t1, t2) in meta[r]:
                 v = torch.empty((nv, 3), dtype=torch.float32, device=dev)
                 f = torch.empty((nf, 3), dtype=torch.int32, device=dev)
                 if nv:
-                    dist.recv(v, src=r)
+                    ops.append(dist.P2POp(dist.irecv, v, r))
                 if nf:
-                    dist.recv(f, src=r)
+                    ops.append(dist.P2POp(dist.irecv, f, r))
                 uv = tex = None
                 if t0 * t1 * t2:
                     uv = torch.empty((nv, 2), dtype=torch.float32, device=dev)
                     tex = torch.empty((t0, t1, t2), dtype=torch.uint8, device=dev)
                     if nv:
-                        dist.recv(uv, src=r)
-                    dist.recv(tex, src=r)
-                out[int(i)] = pack(v, f, uv, tex)
+                        ops.append(dist.P2POp(dist.irecv, uv, r))
+                    ops.append(dist.P2POp(dist.irecv, tex, r))
+                landing.append((int(i), v, f, uv, tex))
     else:
         for i, v, f, uv, tex in mine:
             if v.shape[0]:
-                dist.send(v, dst=dst)
+                ops.append(dist.P2POp(dist.isend, v, dst))
             if f.shape[0]:
-                dist.send(f, dst=dst)
+                ops.append(dist.P2POp(dist.isend, f, dst))
             if tex is not None:
                 if v.shape[0]:
-                    dist.send(uv, dst=dst)
-                dist.send(tex, dst=dst)
+                    ops.append(dist.P2POp(dist.isend, uv, dst))
+                ops.append(dist.P2POp(dist.isend, tex, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for i, v, f, uv, tex in landing:
+        out[i] = pack(v, f, uv, tex)
     return out

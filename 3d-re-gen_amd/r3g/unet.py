@@ -286,7 +286,13 @@ def prepare_aekl_weights(sd, device):
     64 (quant_conv, post_quant_conv); O (and the bias) zero-padded to a multiple of 4 (conv_out: 3 image channels); linear
     layers of the mid block's attention as they are; matrices bf16, vectors f32"""
     out = {}
+    # checkpoints written before diffusers 0.18 name the mid block's attention layers query / key / value / proj_attn
+    # (diffusers' own loader renames them the same way); their weights may also be stored as 1x1 convolutions [C][C][1][1]
+    legacy = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
     for k, t in sd.items():
+        if ".attentions." in k:
+            for old_name, new_name in legacy.items():
+                k = k.replace(old_name, new_name)
         t = t.detach().to(torch.float32)
         if t.ndim == 4:
             if t.shape[-1] == 3:

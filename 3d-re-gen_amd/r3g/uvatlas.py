@@ -104,6 +104,11 @@ def chart_atlas(verts, faces, tex_size, pad=2.0, max_split_rounds=6):
         if not hit.any():
             break
         split = np.where(hit, split.max() + 1 + layer, split)
+    else:
+        # the rounds ran out with patches still stacking layers: `comp` predates the last cut, and nothing has looked at the
+        # patches that cut produced.  The per-face atlas has no such patches (the caller falls back to it on this error)
+        raise ValueError("chart_atlas: patches still stack several layers over one projected spot after %d cuts"
+                         % max_split_rounds)
     chart = comp.astype(np.int64)
     n_chart = int(chart.max()) + 1
     # UV vertices: one per (chart, mesh vertex) pair

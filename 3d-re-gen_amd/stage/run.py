@@ -95,7 +95,11 @@ def default_factory(config, device):
     print("Using '%s' shape generator: %s" % (key, model["id"]))
     path = resolve_weights(config, key, model)
     shapegen = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(path, device=device, **model["args"])
-    texgen = Hunyuan3DPaintPipeline.from_pretrained(path)
+    # the texture models go on this rank's GPU; a snapshot whose texture folders cannot be read (e.g. no
+    # prompt_embeds_empty.safetensors beside a stock checkpoint: INTEGRATION.md) must not take the shape stage down with it
+    texgen = Hunyuan3DPaintPipeline.from_pretrained(path, device=device, strict=bool(config.get("r3g_require_textures", False)))
+    for problem in getattr(texgen, "load_problems", []):
+        print("[WARN] texture model not loaded, continuing without it -- %s" % problem, file=sys.stderr)
     return shapegen, texgen, [FloaterRemover(), DegenerateFaceRemover(), FaceReducer()]
 
 
@@ -240,9 +244,19 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
     results = []
     todo = partition(len(image_paths), rank, world)
     B = objects_per_launch(config)
+    opened = {}
+
+    def open_group(g0):
+        if g0 not in opened:
+            opened[g0] = [Image.open(image_paths[i]).convert("RGBA") for i in todo[g0:g0 + B]]
+        return opened[g0]
     for g0 in range(0, len(todo), B):
         idx = todo[g0:g0 + B]
-        images = [Image.open(image_paths[i]).convert("RGBA") for i in idx]
+        images = open_group(g0)
+        opened.pop(g0)
+        if g0 + B < len(todo) and hasattr(shapegen, "prefetch"):
+            # the next group's crops are decoded and prepared on a host thread while this group is on the GPU
+            shapegen.prefetch(open_group(g0 + B))
         bases = [_stem(image_paths[i]) for i in idx]
         for i, base, (mesh, err, secs) in zip(idx, bases, generate_group(images, bases, shapegen, texgen, cleaners, config,
                                                                           isolate=swallow_errors)):
