@@ -148,17 +148,21 @@ class Hunyuan3DDiTPipeline:
     # front of every group with the GPU idle: `prefetch(images)` starts it, the next `__call__` on the same image objects picks
     # the results up (any other call simply prepares its images itself).  Same functions, same results.
     def _host_prepare(self, image):
+        import time
+        t0 = time.perf_counter()
         x = conditioner_transform(self.prepare_image(image)["image"], self.cfg["cond"]["image_size"])[0]
-        try:
-            return x.pin_memory()
-        except RuntimeError:        # no device runtime (the API-contract tests): plain host memory
-            return x
+        self.timings["host_prepare_s"] = self.timings.get("host_prepare_s", 0.0) + time.perf_counter() - t0
+        return x
 
     def prefetch(self, images):
         """start the host-side preparation of `images` (the next call's objects) on a background thread"""
         import concurrent.futures
         if getattr(self, "_prefetch_pool", None) is None:
-            self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep")
+            # one intra-op thread in the worker (omp_set_num_threads is per calling thread): with the default, the resize's
+            # parallel region started a full OpenMP team beside the HIP runtime's own threads and the main thread's launches
+            # stalled for hundreds of milliseconds per group
+            self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep",
+                                                                        initializer=torch.set_num_threads, initargs=(1,))
         images = list(images) if isinstance(images, (list, tuple)) else [images]
         self._prefetched = (tuple(id(im) for im in images), images,
                             [self._prefetch_pool.submit(self._host_prepare, im) for im in images])

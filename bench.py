@@ -426,6 +426,7 @@ def main():
             out["mc_parity"] = "exact" if same else "MISMATCH"
             bad = not same
     if rank == 0:
+        out["host_prepare_ms_per_object"] = 1000.0 * pipe.timings.get("host_prepare_s", 0.0) / max(1, n_local)
         print(json.dumps(out))
     if bad:
         raise SystemExit("bench.py: the timed object's mesh differs from the marching-cubes oracle's mesh of the same grid")
