@@ -34,6 +34,15 @@ namespace {
 
 constexpr int BK = 64;
 
+// compile-time loop (the bodies are separate inlined calls: no reliance on the loop unroller for large bodies)
+template <int B, int E, int S, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + S, E, S>(f);
+    }
+}
+
 // one operand tile: ROWS rows x 64 k, in pieces of 1 KiB (8 rows), spread over NW waves
 template <bool GLDS, int NW, int ROWS>
 __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int64_t ld, int row0, int rows_valid,
@@ -79,13 +88,16 @@ template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
                                               int wc, int lane, char* lds_wave = nullptr, const f32x4* bias_pre = nullptr) {
     constexpr int WROWS = MI * 16;
-    static_assert(MI % PI == 0 && (EPI != EPI_QKV || PI == MI), "scratch passes");
+    static_assert(MI % PI == 0, "scratch passes");
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
         // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
         const QkvEpi& e = p.qkv;
         const int g = (n0 + wc * 64) >> 6;
-        if (n0 + wc * 64 >= p.N) return;
+        if (n0 + wc * 64 >= p.N) {
+            if (VM0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the wait every wave owes the next tile's first k-tile)
+            return;
+        }
         int type, head;  // 0 q, 1 k, 2 v
         if (e.layout == QKV_KHD) { type = g / e.heads; head = g - type * e.heads; }
         else if (e.layout == QKV_HEAD_QKV) { head = g / 3; type = g - head * 3; }
@@ -132,8 +144,89 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (do_norm && nw) nw4[j] = *reinterpret_cast<const f32x4*>(nw + j * 16 + dbase);
             if (do_norm && e.norm == QKN_LAYERNORM && nb) nb4[j] = *reinterpret_cast<const f32x4*>(nb + j * 16 + dbase);
         }
+        constexpr int PROWS = PI * 16;
+        // one pass of PI 16-row groups through the wave's scratch (PROWS x 128 bytes): rows ip*16 .. of the wave's sub-tile
+        auto flush_pass = [&](const int ip) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (VM0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // destination of tile row `rr` (token m): attention batch and row, or -1 when the row is dropped
+            auto map_row = [&](int m, int& ob, int64_t& drow) {
+                ob = batch;
+                drow = (int64_t)e.dst_row0 + m;
+                if (m >= p.M) return false;
+                if (sg_n == 0) return true;
+                bool hit = false;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+                for (int sgi = 0; sgi < 3; ++sgi)
+                    if (sgi < sg_n && m >= sg_m0[sgi] && m < sg_m1[sgi]) {
+                        hit = true;
+                        ob = sg_b[sgi];
+                        drow = (int64_t)sg_d[sgi] + (m - sg_m0[sgi]);
+                    }
+                return hit;
+            };
+            const int mw = m0 + wr * WROWS + ip * 16;
+            if (type < 2) {
+                // 8 tokens x 128 contiguous bytes per store instruction (a token's 64 dims are one cache line)
+                const int cc = lane & 7;
+#pragma unroll
+                for (int t = 0; t < PROWS / 8; ++t) {
+                    const int rr = t * 8 + (lane >> 3);
+                    int ob;
+                    int64_t drow;
+                    if (!map_row(mw + rr, ob, drow)) continue;
+                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
+                                                : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
+                    *reinterpret_cast<uint4*>(base + cc * 8) = dv;
+                }
+            } else {
+                // V^T[dim][key position]: a lane takes the 8 tokens that are contiguous in the destination (vt_key_pos:
+                // tokens 16u + 4h + {0..3} and 16u + 8 + 4h + {0..3} = positions 16u + 8h + {0..7}, 16 bytes) when the
+                // whole 16-token group stays together there, otherwise token by token (segment boundaries, ragged ends)
+                constexpr int CPR = PROWS / 8;   // 16-byte chunks per dim row of the LDS image
+#pragma unroll
+                for (int t = 0; t < 64 / (64 / CPR); ++t) {
+                    const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
+                    const int u = ck >> 1, h8 = (ck & 1) * 8;
+                    const int sw = (d >> 2) & (CPR - 1);
+                    const char* drow_lds = lds_wave + d * (PROWS * 2);
+                    const uint2 lo = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u) ^ sw) << 4) + h8);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
+                    const int mfirst = mw + 16 * u;
+                    int ob0, ob15;
+                    int64_t dr0, dr15;
+                    const bool ok0 = map_row(mfirst, ob0, dr0), ok15 = map_row(mfirst + 15, ob15, dr15);
+                    const int64_t lk = e.Lk_pad;
+                    if (ok0 && ok15 && ob0 == ob15 && dr15 == dr0 + 15 && ((dr0 & 15) | (lk & 7)) == 0) {
+                        uint16_t* dst = e.Vt + (((int64_t)ob0 * e.heads + head) * 64 + d) * lk + dr0 + h8;
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    } else {
+                        const uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int tk = 16 * u + (k < 4 ? (h8 >> 1) + k : 8 + (h8 >> 1) + (k - 4));
+                            int ob;
+                            int64_t dr;
+                            if (map_row(mw + tk, ob, dr))
+                                e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + vt_key_pos(dr)] =
+                                    (uint16_t)(w4[k >> 1] >> ((k & 1) * 16));
+                        }
+                    }
+                }
+            }
+            if (PI != MI) {      // the next pass reuses the scratch
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        // passes of PI row groups: the groups of a pass are staged in the scratch (or stored directly), then the pass leaves
+        static_for<0, MI, PI>([&](auto IPC) __attribute__((always_inline)) {
+        constexpr int ip = decltype(IPC)::value;
+#pragma unroll
+        for (int ii = 0; ii < PI; ++ii) {
+            const int i = ip + ii;
             const int m = m0 + wr * WROWS + i * 16 + (lane & 15);
             f32x4 v[4];
 #pragma unroll
@@ -169,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (lds_wave != nullptr) {
                 // stage the normalised tile in the wave's LDS scratch: Q / K as [token][64 dims] (16-byte chunks
                 // swizzled by the token), V as [dim][token] (chunks of 8 tokens swizzled by the dim group)
-                const int r = i * 16 + (lane & 15), q = lane >> 4;
+                const int r = ii * 16 + (lane & 15), q = lane >> 4;
                 if (type < 2) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -185,8 +278,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const int d = j * 16 + q * 4 + c;
-                            const int chunk = (r >> 3) ^ ((d >> 2) & (WROWS / 8 - 1));
-                            *reinterpret_cast<uint16_t*>(lds_wave + d * (WROWS * 2) + chunk * 16 + (r & 7) * 2) =
+                            const int chunk = (r >> 3) ^ ((d >> 2) & (PROWS / 8 - 1));
+                            *reinterpret_cast<uint16_t*>(lds_wave + d * (PROWS * 2) + chunk * 16 + (r & 7) * 2) =
                                 (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
                         }
                 }
@@ -226,76 +319,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
             }
         }
-        if (lds_wave != nullptr) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // destination of tile row `rr` (token m): attention batch and row, or -1 when the row is dropped
-            auto map_row = [&](int m, int& ob, int64_t& drow) {
-                ob = batch;
-                drow = (int64_t)e.dst_row0 + m;
-                if (m >= p.M) return false;
-                if (sg_n == 0) return true;
-                bool hit = false;
-#pragma unroll
-                for (int sgi = 0; sgi < 3; ++sgi)
-                    if (sgi < sg_n && m >= sg_m0[sgi] && m < sg_m1[sgi]) {
-                        hit = true;
-                        ob = sg_b[sgi];
-                        drow = (int64_t)sg_d[sgi] + (m - sg_m0[sgi]);
-                    }
-                return hit;
-            };
-            const int mw = m0 + wr * WROWS;
-            if (type < 2) {
-                // 8 tokens x 128 contiguous bytes per store instruction (a token's 64 dims are one cache line)
-                const int cc = lane & 7;
-#pragma unroll
-                for (int t = 0; t < WROWS / 8; ++t) {
-                    const int rr = t * 8 + (lane >> 3);
-                    int ob;
-                    int64_t drow;
-                    if (!map_row(mw + rr, ob, drow)) continue;
-                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
-                    uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
-                                                : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
-                    *reinterpret_cast<uint4*>(base + cc * 8) = dv;
-                }
-            } else {
-                // V^T[dim][key position]: a lane takes the 8 tokens that are contiguous in the destination (vt_key_pos:
-                // tokens 16u + 4h + {0..3} and 16u + 8 + 4h + {0..3} = positions 16u + 8h + {0..7}, 16 bytes) when the
-                // whole 16-token group stays together there, otherwise token by token (segment boundaries, ragged ends)
-                constexpr int CPR = WROWS / 8;   // 16-byte chunks per dim row of the LDS image
-#pragma unroll
-                for (int t = 0; t < 64 / (64 / CPR); ++t) {
-                    const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
-                    const int u = ck >> 1, h8 = (ck & 1) * 8;
-                    const int sw = (d >> 2) & (CPR - 1);
-                    const char* drow_lds = lds_wave + d * (WROWS * 2);
-                    const uint2 lo = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u) ^ sw) << 4) + h8);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
-                    const int mfirst = mw + 16 * u;
-                    int ob0, ob15;
-                    int64_t dr0, dr15;
-                    const bool ok0 = map_row(mfirst, ob0, dr0), ok15 = map_row(mfirst + 15, ob15, dr15);
-                    const int64_t lk = e.Lk_pad;
-                    if (ok0 && ok15 && ob0 == ob15 && dr15 == dr0 + 15 && ((dr0 & 15) | (lk & 7)) == 0) {
-                        uint16_t* dst = e.Vt + (((int64_t)ob0 * e.heads + head) * 64 + d) * lk + dr0 + h8;
-                        *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    } else {
-                        const uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int tk = 16 * u + (k < 4 ? (h8 >> 1) + k : 8 + (h8 >> 1) + (k - 4));
-                            int ob;
-                            int64_t dr;
-                            if (map_row(mw + tk, ob, dr))
-                                e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + vt_key_pos(dr)] =
-                                    (uint16_t)(w4[k >> 1] >> ((k & 1) * 16));
-                        }
-                    }
-                }
-            }
-        }
+        if (lds_wave != nullptr) flush_pass(ip);
+        });
         return;
     }
     // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}.
@@ -1328,7 +1353,14 @@ hipError_t launch_gemm8_fp8(const GemmArgs& p, const float* scale_a, const float
 // kernel; this form removes most of the prologue and part of the epilogue wait (bf16 outputs -2 .. -9 %).  The fp32
 // read-modify-write epilogue is bound by HBM (1.3 GB per launch at ~3.5 TB/s) and stays on gemm8_kernel.
 // Same k-order and MFMA shape as gemm8_kernel: bit-identical results.
-template <int EPI>
+// EARLY (round 4, bf16-output epilogues): the wait for the next tile's first k-tile sits inside the epilogue, in front of its
+// first global store (the pieces were issued before the epilogue began and have had its arithmetic to land), and the loop is
+// entered WITHOUT a vmcnt: round 3's vmcnt(6) at the loop top also waited for the acknowledgements of the epilogue's stores,
+// which are older than the six pieces of k-tile 1 (stamps: 2-5 k cycles per tile).  The first counted wait of the k-loop
+// (phase 4) retires k-tile 1 and the stores together, ~2 k cycles later.  Safe with stores in the count: loads complete in
+// order among themselves, so "at most six operations outstanding" still implies that every load older than the six newest
+// loads has landed, whatever the stores do.
+template <int EPI, bool EARLY = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, MI = 8;
@@ -1514,11 +1546,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     locate_u(my, cur, nk);
     set_sources(cur);
     stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+    bool first_tile = true;
     for (;;) {
         // k-tile 0 is on its way (and, after the first tile, the previous tile's stores); k-tile 1 follows as in gemm8_kernel.
         // vmcnt(6) retires everything older than these six pieces -- exact whatever the epilogue issued.
         stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (!EARLY || first_tile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        first_tile = false;
         R3G_BAR();
         if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
         int t = 0;
@@ -1553,9 +1587,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         }
         {
             const GemmArgs& pp = args_of(done.second);
-            gemm_epilogue<EPI, MI, true, 2>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane,
-                                            pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr,
-                                            (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) ? bias_pre : nullptr);
+            gemm_epilogue<EPI, MI, true, 2, EARLY>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane,
+                                                   pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr,
+                                                   (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) ? bias_pre : nullptr);
+            // (last tile: no next k-tile was staged, the wait inside the epilogue found nothing -- harmless)
         }
         if (!more) break;
         // the staging pointers are recomputed rather than kept alive across the epilogue (16 registers it needs); the
@@ -1569,6 +1604,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     }
 }
 
+bool g_gemm_persistent_qkv = false;  // fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel (measured: +17 ms per object, off)
+bool g_gemm_early_wait = false;  // persistent phased kernel, bf16 outputs: wait for the next tile's first k-tile inside the epilogue (measured: no effect, off)
+
 template <int EPI>
 hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipStream_t s) {
     int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
@@ -1576,12 +1614,18 @@ hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipS
     const int rounds = (tiles + num_cu - 1) / num_cu;
     const int grid = (tiles + rounds - 1) / rounds;    // every workgroup gets `rounds` tiles (the last ones one fewer)
     const size_t lds = 163840;
-    auto k = gemm8p_kernel<EPI>;
+    constexpr bool kBf16Out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_QKV;
+    auto k = gemm8p_kernel<EPI, false>;
+    auto ke = gemm8p_kernel<EPI, kBf16Out>;
     static int state = 0;   // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS
-    if (state == 0)
+    if (state == 0) {
         state = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+        if (state > 0 && kBf16Out)
+            state = hipFuncSetAttribute((const void*)ke, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+    }
     if (state < 0) { (void)hipGetLastError(); return hipErrorNotSupported; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles);
+    if (kBf16Out && g_gemm_early_wait && p.wide_epilogue) { hipLaunchKernelGGL(ke, dim3(grid), dim3(512), lds, s, p, p2, tiles); }
+    else { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles); }
     return hipGetLastError();
 }
 
@@ -1739,14 +1783,16 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
     }
     if (waves == 13) waves = 11;
     if ((waves == 11 || waves == 12) && p.K % 128 == 0 && (p2.M == 0 || p2.K % 128 == 0)) {   // phased 256x256x64
-        if constexpr (EPI != EPI_QKV) {
+        {
             // persistent form when a CU gets more than one tile and the output is bf16 (waves == 12 forces it for any
             // epilogue but QKV); it needs 160 KiB of LDS per workgroup
             long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
             if (p2.M > 0) tiles += (long)((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
             // read-modify-write epilogues: bit 0 of gemm_persistent_resid admits the fp32 residual form, bit 1 the bf16 one
+            // (round 4: the fused QKV epilogue runs in passes of 32 rows through the persistent kernel's 4 KiB of scratch per wave)
             const bool resid_ok = (EPI != EPI_RESID_F32 || (g_gemm_persistent_resid & 1)) &&
-                                  (EPI != EPI_RESID_BF16 || (g_gemm_persistent_resid & 2));
+                                  (EPI != EPI_RESID_BF16 || (g_gemm_persistent_resid & 2)) &&
+                                  (EPI != EPI_QKV || (g_gemm_persistent_qkv && p.wide_epilogue));
             if (p.K >= 256 && (p2.M == 0 || p2.K >= 256) &&
                 (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && resid_ok && EPI != EPI_F32))) {
                 const hipError_t e = launch_gemm8p<EPI>(p, p2, g_num_cu, s);
@@ -1778,6 +1824,8 @@ void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
+void gemm_set_early_wait(bool on) { g_gemm_early_wait = on; }
+void gemm_set_persistent_qkv(bool on) { g_gemm_persistent_qkv = on; }
 void gemm_set_stream(int mode) { g_gemm_stream = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void gemm_set_config(int waves) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 14 || waves == 16 || waves == 32) g_gemm_waves = waves;
