@@ -24,8 +24,11 @@ import os
 
 import numpy as np
 
-# (elevation, azimuth, blend weight) of upstream's six candidate views
-DEFAULT_VIEWS = [(0, 0, 1.0), (0, 90, 0.1), (0, 180, 0.5), (0, 270, 0.1), (90, 0, 0.05), (-90, 0, 0.05)]
+# (elevation, azimuth, blend weight) of upstream's six candidate views.  [UPSTREAM-RECALLED] Hunyuan3DTexGenConfig:
+# candidate_camera_azims = [0, 90, 180, 270, 0, 180], candidate_camera_elevs = [0, 0, 0, 0, 90, -90],
+# candidate_view_weights = [1, 0.1, 0.5, 0.1, 0.05, 0.05] -- the view from below is taken at azimuth 180 (camera index 37 of
+# the multiview model; rounds 2-3 had it at azimuth 0 = index 39).  Unpinned: to be checked against the public source.
+DEFAULT_VIEWS = [(0, 0, 1.0), (0, 90, 0.1), (0, 180, 0.5), (0, 270, 0.1), (90, 0, 0.05), (-90, 180, 0.05)]
 
 
 def view_rotation(elev_deg, azim_deg):
@@ -50,9 +53,10 @@ class Hunyuan3DPaintPipeline:
 
     def __init__(self, texture_size=None, render_size=None, multiview_model=None, views=None, cos_threshold=0.1,
                  depth_edge=0.02, power=4.0, dilate_iters=8, device=None, atlas=None, delight_model=None):
-        # upstream: texture_size 2048, render_size 2048; R3G_TEX_SIZE / R3G_TEX_RENDER override the defaults (tests)
+        # [UPSTREAM-RECALLED] Hunyuan3DTexGenConfig: texture_size 2048, render_size 2048; R3G_TEX_SIZE / R3G_TEX_RENDER override
+        # the defaults (tests).  (Rounds 2-3 rendered at 1024.)
         self.texture_size = int(texture_size or os.environ.get("R3G_TEX_SIZE", 2048))
-        self.render_size = int(render_size or os.environ.get("R3G_TEX_RENDER", 1024))
+        self.render_size = int(render_size or os.environ.get("R3G_TEX_RENDER", 2048))
         self.multiview_model = multiview_model
         # upstream: self.models['delight_model'] = Light_Shadow_Remover(config), applied to the image first thing in __call__;
         # here an instance of hy3dgen.texgen.utils.dehighlight_utils.Light_Shadow_Remover (HIP UNet + VAE) when the caller has one

@@ -62,8 +62,15 @@ class MultiviewPipeline:
     unconditional branch: zero reference latents with ref_scale 0), combined as uncond + g (cond - uncond); the views are decoded
     one by one.  Latents, conditioning latents and noise stay in HBM as rows for the whole loop."""
 
-    def __init__(self, unet, vae, scaling_factor=0.18215, prediction_type="epsilon"):
+    def __init__(self, unet, vae, scaling_factor=0.18215, prediction_type="epsilon", uncond_context="zeros"):
+        """uncond_context: the text context of the UNCONDITIONAL branch of classifier-free guidance.  "zeros" (default):
+        [UPSTREAM-RECALLED] HunyuanPaintPipeline sets negative_prompt_embeds = zeros_like(prompt_embeds) -- the branch runs without
+        the reference attention AND on an all-zero context; "learned": the learned embedding in both branches (rounds 2-3).
+        Unpinned: to be checked against the public source"""
         from . import sched as _sched
+        if uncond_context not in ("zeros", "learned"):
+            raise ValueError("uncond_context must be 'zeros' or 'learned'")
+        self.uncond_context = uncond_context
         self.unet, self.vae = unet, vae
         self.scaling_factor = float(scaling_factor)
         self.scheduler = _sched.EulerAncestralDiscrete(prediction_type=prediction_type, timestep_spacing="trailing")
@@ -100,6 +107,7 @@ class MultiviewPipeline:
         self.unet.reference_pass(ref_latents, camera_info_ref)
         labels = None if camera_info_gen is None else [int(v) + self.unet.max_num_ref_image for v in camera_info_gen]
         ctx = self.unet.text_gen[0].to(dev, torch.bfloat16).contiguous()
+        ctx_u = torch.zeros_like(ctx) if self.uncond_context == "zeros" else ctx
         sch = self.scheduler.set_timesteps(steps)
         x = _unet.to_rows(noise["latents"].to(dev)) * sch.init_noise_sigma
         step_noise = [_unet.to_rows(e.to(dev)) for e in noise["steps"]]
@@ -112,7 +120,7 @@ class MultiviewPipeline:
             sch.model_input(x, cond_rows, i, out=inp)
             gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=2, out=eps_c)
             if guidance_scale > 1.0:
-                gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=0, out=eps_u)
+                gen.forward_mv_rows(inp, n, h, w, t, ctx_u, class_labels=labels, flags=0, out=eps_u)
                 sch.cfg_combine(eps_u, eps_c, guidance_scale, out=eps_c)
             sch.step(x, eps_c, step_noise[i], i)
         if output == "latent":

@@ -97,7 +97,11 @@ def default_factory(config, device):
     shapegen = Hunyuan3DDiTFlowMatchingPipeline.from_pretrained(path, device=device, **model["args"])
     # the texture models go on this rank's GPU; a snapshot whose texture folders cannot be read (e.g. no
     # prompt_embeds_empty.safetensors beside a stock checkpoint: INTEGRATION.md) must not take the shape stage down with it
-    texgen = Hunyuan3DPaintPipeline.from_pretrained(path, device=device, strict=bool(config.get("r3g_require_textures", False)))
+    # private key `r3g_texture_weights`: the folder that holds upstream's two texture sub-folders (hunyuan3d-delight-v2-0,
+    # hunyuan3d-paint-v2-0) when it is not the shape model's snapshot -- e.g. shape weights "synthetic:..." beside real or
+    # test-written texture checkpoints
+    tex_path = config.get("r3g_texture_weights") or path
+    texgen = Hunyuan3DPaintPipeline.from_pretrained(tex_path, device=device, strict=bool(config.get("r3g_require_textures", False)))
     for problem in getattr(texgen, "load_problems", []):
         print("[WARN] texture model not loaded, continuing without it -- %s" % problem, file=sys.stderr)
     return shapegen, texgen, [FloaterRemover(), DegenerateFaceRemover(), FaceReducer()]
@@ -245,6 +249,11 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
     todo = partition(len(image_paths), rank, world)
     B = objects_per_launch(config)
     opened = {}
+    # GLB encoding (PNG deflate of the texture, 50-80 ms per object) runs on a host thread while the next object is on the GPU;
+    # the mesh's arrays are brought to the host first, on this thread
+    import concurrent.futures
+    writer = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-glb-writer")
+    pending = []
 
     def open_group(g0):
         if g0 not in opened:
@@ -261,13 +270,38 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
         for i, base, (mesh, err, secs) in zip(idx, bases, generate_group(images, bases, shapegen, texgen, cleaners, config,
                                                                           isolate=swallow_errors)):
             if err is None:
-                out_path = export_mesh(mesh, base, output_folder)
-                print("Saved %s to %s in %.2f seconds." % (base, out_path, secs))
-                results.append((i, image_paths[i], "ok", secs))
+                try:
+                    _ = (mesh.vertices, mesh.faces, getattr(mesh, "uv", None), getattr(mesh, "texture", None))   # device -> host
+                    pending.append((i, base, secs, writer.submit(export_mesh, mesh, base, output_folder)))
+                except Exception as e:        # noqa: BLE001
+                    if not swallow_errors:
+                        raise
+                    print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
+                    results.append((i, image_paths[i], "error: %s" % e, secs))
             else:
                 print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
                 results.append((i, image_paths[i], "error: %s" % err, secs))
+        done_now, pending = [p for p in pending if p[3].done()], [p for p in pending if not p[3].done()]
+        for item in done_now:
+            _collect_export(item, results, image_paths, rank, swallow_errors)
+    for item in pending:
+        _collect_export(item, results, image_paths, rank, swallow_errors)
+    writer.shutdown()
+    results.sort(key=lambda r: r[0])
     return results, texture_state(texgen)
+
+
+def _collect_export(item, results, image_paths, rank, swallow_errors):
+    i, base, secs, fut = item
+    try:
+        out_path = fut.result()
+        print("Saved %s to %s in %.2f seconds." % (base, out_path, secs))
+        results.append((i, image_paths[i], "ok", secs))
+    except Exception as e:        # noqa: BLE001
+        if not swallow_errors:
+            raise
+        print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, e))
+        results.append((i, image_paths[i], "error: %s" % e, secs))
 
 
 def run_distributed(config, input_folder, output_folder, rank, world, factory):

@@ -27,8 +27,10 @@ def encode(vae, images, noise, scaling_factor):
 
 @torch.no_grad()
 def multiview_paint(unet, vae, ref_images, normal_imgs, position_imgs, camera_info_gen, camera_info_ref, num_inference_steps, noise,
-                    guidance_scale=2.0, scaling_factor=0.18215, output="image"):
-    """unet: oracle.unet2p5d_torch.UNet2p5DConditionModel; vae: oracle.aekl_torch.AutoencoderKL; noise as r3g.multiview"""
+                    guidance_scale=2.0, scaling_factor=0.18215, output="image", uncond_context="zeros"):
+    """unet: oracle.unet2p5d_torch.UNet2p5DConditionModel; vae: oracle.aekl_torch.AutoencoderKL; noise as r3g.multiview.
+    uncond_context "zeros": [UPSTREAM-RECALLED] negative_prompt_embeds = zeros_like(prompt_embeds) in the unconditional branch;
+    "learned": the learned embedding in both branches (what rounds 2-3 restated)"""
     ts, sig = trailing_tables(num_inference_steps)
     ref_latents = encode(vae, ref_images, noise["ref"], scaling_factor)
     nl = encode(vae, normal_imgs, noise["normal"], scaling_factor)
@@ -40,7 +42,7 @@ def multiview_paint(unet, vae, ref_images, normal_imgs, position_imgs, camera_in
         xs = x / (float(sig[i]) ** 2 + 1) ** 0.5
         eps = unet(xs, float(t), nl, pl, cond, cam)
         if guidance_scale > 1.0:
-            eps_u = unet(xs, float(t), nl, pl, cond, cam, ref_scale=0.0)
+            eps_u = unet(xs, float(t), nl, pl, cond, cam, ref_scale=0.0, zero_context=uncond_context == "zeros")
             eps = eps_u + guidance_scale * (eps - eps_u)
         x = P.euler_ancestral_step(x, eps, noise["steps"][i], sig[i], sig[i + 1])
     if output == "latent":

@@ -100,13 +100,17 @@ class UNet2p5DConditionModel(nn.Module):
         return cond
 
     @torch.no_grad()
-    def forward(self, sample, timestep, normal_imgs, position_imgs, cond, camera_info_gen=None, mva_scale=1.0, ref_scale=1.0):
-        """sample / normal_imgs / position_imgs [n_gen, 4, h, w] (one object: b = 1) -> noise prediction [n_gen, 4, h, w]"""
+    def forward(self, sample, timestep, normal_imgs, position_imgs, cond, camera_info_gen=None, mva_scale=1.0, ref_scale=1.0,
+                zero_context=False):
+        """sample / normal_imgs / position_imgs [n_gen, 4, h, w] (one object: b = 1) -> noise prediction [n_gen, 4, h, w];
+        zero_context: an all-zero text context instead of the learned embedding (the unconditional branch, see mvpaint_torch)"""
         n = sample.shape[0]
         x = torch.cat([sample, normal_imgs, position_imgs], dim=1)
         self.ctl.clear()
         self.ctl.update(mode="r", num_in_batch=n, condition_embed_dict=cond, mva_scale=mva_scale, ref_scale=ref_scale)
         ctx = self.unet.learned_text_clip_gen.expand(n, -1, -1)
+        if zero_context:
+            ctx = torch.zeros_like(ctx)
         cls = None
         if camera_info_gen is not None:
             cls = self.unet.class_embedding(camera_info_gen + self.max_num_ref_image)

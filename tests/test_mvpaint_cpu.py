@@ -17,9 +17,11 @@ from hy3dgen.texgen.utils import multiview_utils as MU  # noqa: E402
 
 
 def test_camera_indices_fit_the_embedding_table():
-    views = [(0, 0), (0, 90), (0, 180), (0, 270), (90, 0), (-90, 0)]
+    from hy3dgen.texgen.pipelines import DEFAULT_VIEWS
+    views = [(e, a) for e, a, _ in DEFAULT_VIEWS]
+    assert views == [(0, 0), (0, 90), (0, 180), (0, 270), (90, 0), (-90, 180)]     # [UPSTREAM-RECALLED] the view from below at azimuth 180
     idx = [MU.camera_index(e, a) for e, a in views]
-    assert idx == [21, 12, 15, 18, 43, 39] and len(set(idx)) == 6
+    assert idx == [21, 12, 15, 18, 43, 37] and len(set(idx)) == 6
     every = {MU.camera_index(e, a) for e in (-20, 0, 20) for a in range(0, 360, 30)} | \
             {MU.camera_index(e, a) for e in (-90, 90) for a in range(0, 360, 90)}
     assert every == set(range(44))                       # 12 x 3 rings + 4 x 2 poles: upstream's max_num_gen_image
@@ -68,7 +70,7 @@ def test_oracle_loop_guidance_one_skips_the_unconditional_branch():
 class _StubPipeline:
     def __call__(self, ref, normal, position, cams, camera_info_ref, num_inference_steps, generator):
         assert ref.shape == (1, 3, 512, 512) and normal.shape == (6, 3, 512, 512) and position.shape == normal.shape
-        assert cams == [21, 12, 15, 18, 43, 39] and camera_info_ref == [0] and num_inference_steps == 30
+        assert cams == [21, 12, 15, 18, 43, 37] and camera_info_ref == [0] and num_inference_steps == 30
         assert generator.initial_seed() == 0 and float(normal.min()) >= -1 and float(normal.max()) <= 1
         return normal                                    # echo the normal maps
 
@@ -78,7 +80,7 @@ def test_multiview_diffusion_net_bookkeeping():
     rng = np.random.default_rng(0)
     ctl = [Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8), "RGB") for _ in range(12)]
     net = MU.Multiview_Diffusion_Net(pipeline=_StubPipeline())
-    out = net(Image.fromarray(rng.integers(0, 255, (80, 80, 3), dtype=np.uint8), "RGB"), ctl, [21, 12, 15, 18, 43, 39])
+    out = net(Image.fromarray(rng.integers(0, 255, (80, 80, 3), dtype=np.uint8), "RGB"), ctl, [21, 12, 15, 18, 43, 37])
     assert len(out) == 6 and all(o.size == (512, 512) and o.mode == "RGB" for o in out)
     assert np.abs(np.asarray(out[2]).astype(int) - np.asarray(ctl[2].resize((512, 512))).astype(int)).max() <= 1
     with pytest.raises(ValueError):

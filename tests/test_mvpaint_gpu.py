@@ -123,7 +123,7 @@ def test_upstream_flow_through_the_paint_pipeline(pair):
     img[..., 3] = np.where((xx - 47.5) ** 2 + (yy - 47.5) ** 2 < 40 ** 2, 255, 0)
     pipe = Hunyuan3DPaintPipeline(texture_size=256, render_size=128, multiview_model=Spy(pipeline=pair.pipe), delight_model=delight)
     out = pipe(Mesh(v, f), image=Image.fromarray(img, "RGBA"))
-    assert calls["n_control"] == 12 and calls["cams"] == [21, 12, 15, 18, 43, 39]
+    assert calls["n_control"] == 12 and calls["cams"] == [21, 12, 15, 18, 43, 37]
     n0, p0 = calls["normal0"], calls["position0"]
     assert n0.shape == (64, 64, 3) and (n0[0, 0] == 255).all() and (p0[0, 0] == 255).all()       # white outside the silhouette
     c = n0[32, 32].astype(int)                                                                    # front view, centre: n = +z

@@ -51,19 +51,25 @@ def test_stage_script_writes_glbs(tmp_path):
 def test_configs1_literally_eight_crops_full_model(tmp_path):
     """BASELINE.json configs[1] as written: 1 scene / 8 object crops, Hunyuan3D-2 base dims at FULL depth (16 + 32 blocks,
     DINOv2-g 40 layers, VAE 16 layers), 50 steps x CFG 2, 256^3 octree grid, through the drop-in stage script (reference
-    call src/2d_to_3d_models/run.py:77-84 with src/config.yaml's values); every GLB is checked."""
+    call src/2d_to_3d_models/run.py:77-84 with src/config.yaml's values); every GLB is checked.  The texture stage
+    (run.py:97, built at :126-128) runs upstream's WHOLE flow here: the two diffusion models are loaded by the stage's default
+    factory from checkpoint sub-folders (written from the oracle's small random models: there are no real weights), so the
+    baked views are the multiview model's, not the input crop."""
     sys.path.insert(0, ROOT)
     from bench import synthetic_crop
     from r3g.mesh import load_glb
     from gltf_validate import validate_glb
+    from tex_ckpt_support import write_checkpoints
     inp, out = tmp_path / "prepped", tmp_path / "out"
     inp.mkdir()
+    write_checkpoints(str(tmp_path / "texture_weights"), seed=3)
     for i in range(8):
         synthetic_crop(i).save(inp / ("obj__(%d, %d).png" % (i, 10 * i)))
     cfg = {"mini": False, "num_inf_steps_hy": 50, "octree_resolution_hy": 256, "num_chunks_hy": 16000, "seed": 1234567,
            "remesh": False, "input_folder_hy": str(tmp_path / "unused"), "output_folder_hy": str(out), "use_banana": True,
            "prepped_for_hunyuan": str(inp), "jobs_per_gpu": 1, "use_all_available_cuda": False,
-           "r3g_weights": "synthetic:{model}"}
+           "r3g_weights": "synthetic:{model}", "r3g_texture_weights": str(tmp_path / "texture_weights"),
+           "r3g_require_textures": True}
     cfgp = tmp_path / "config.yaml"
     cfgp.write_text(yaml.safe_dump(cfg))
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
@@ -76,6 +82,7 @@ def test_configs1_literally_eight_crops_full_model(tmp_path):
     assert sorted(os.listdir(out)) == sorted("obj__(%d, %d)" % (i, 10 * i) for i in range(8))
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
     assert rep["objects"] == 8 and rep["ok"] == 8 and rep["failed"] == []
+    assert rep["textured"] is True and "multiview diffusion model" in rep["texture_source"] and "delighted" in rep["texture_source"]
     distinct = set()
     for stem in os.listdir(out):
         data = (out / stem / (stem + ".glb")).read_bytes()

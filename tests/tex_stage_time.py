@@ -61,7 +61,7 @@ def main():
     out = timed("whole_stage_ms", lambda: pipe(mesh, image=image))
     timed("delight_only_ms", lambda: delight(image))
     nm = [Image.new("RGB", (512, 512), (128, 128, 255))] * 6
-    timed("multiview_only_ms", lambda: net(image.convert("RGB"), nm + nm, [21, 12, 15, 18, 43, 39]))
+    timed("multiview_only_ms", lambda: net(image.convert("RGB"), nm + nm, [21, 12, 15, 18, 43, 37]))
     print(json.dumps({"what": "texture stage at upstream's sizes, both diffusion models on the HIP blocks, random weights",
                       "faces": int(len(f)), "texture": list(out.texture.shape), "delight_steps": delight.steps, "multiview_steps": net.steps,
                       "views": 6, "view_size": net.view_size, "guidance_scale": 2.0, "setup_seconds_cpu_weight_synthesis": round(setup, 1),
