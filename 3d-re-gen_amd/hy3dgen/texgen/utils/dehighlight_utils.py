@@ -114,6 +114,34 @@ def recorrect_rgb(src, target, alpha, scale=0.95):
     return np.concatenate([src if keep_src else out, alpha], axis=-1)
 
 
+def empty_prompt_embedding(path, prompt=""):
+    """The text conditioning of the delighting model.  Upstream's Light_Shadow_Remover calls its InstructPix2Pix pipeline with the
+    prompt "" every time, so the CLIP text encoder's output is ONE constant per checkpoint: it is computed once, when the
+    checkpoint is loaded, and never on the per-object path.  Sources, in this order:
+      * `<path>/prompt_embeds_empty.safetensors` (key "prompt_embeds"), when it is there (tools/make_prompt_embeds.py writes it);
+      * the checkpoint's own `tokenizer/` and `text_encoder/` (the stock snapshot layout) through `transformers` on the host,
+        exactly as diffusers' `encode_prompt` does: `text_encoder(tokenizer(prompt, padding="max_length",
+        max_length=model_max_length, truncation=True).input_ids)[0]` -- the last hidden state, fp32.
+    -> f32 [1, tokens, dim]"""
+    import torch
+    pe = os.path.join(path, "prompt_embeds_empty.safetensors")
+    if os.path.exists(pe) and prompt == "":
+        from safetensors.torch import load_file
+        emb = load_file(pe)["prompt_embeds"]
+        return emb.reshape(1, emb.shape[-2], emb.shape[-1]).float()
+    tok_dir, enc_dir = os.path.join(path, "tokenizer"), os.path.join(path, "text_encoder")
+    if not (os.path.isdir(tok_dir) and os.path.isdir(enc_dir)):
+        raise FileNotFoundError("%s has neither prompt_embeds_empty.safetensors nor tokenizer/ + text_encoder/: the delighting model "
+                                "needs the text embedding of the empty prompt (INTEGRATION.md)" % path)
+    from transformers import CLIPTextModel, CLIPTokenizer
+    tok = CLIPTokenizer.from_pretrained(tok_dir)
+    enc = CLIPTextModel.from_pretrained(enc_dir).to(torch.float32).eval()
+    ids = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+    with torch.no_grad():
+        emb = enc(ids)[0]
+    return emb.reshape(1, emb.shape[-2], emb.shape[-1]).float().contiguous()
+
+
 class Light_Shadow_Remover:
     cfg_image = 1.5      # image_guidance_scale (inert while cfg_text <= 1: diffusers then runs no guidance at all)
     cfg_text = 1.0       # guidance_scale
@@ -141,14 +169,8 @@ class Light_Shadow_Remover:
         or .bin), scheduler/scheduler_config.json (prediction_type) and `prompt_embeds_empty.safetensors` (key "prompt_embeds":
         the text encoder's last hidden state for the prompt "", computed once with the checkpoint's own tokenizer / text_encoder
         -- INTEGRATION.md)"""
-        from safetensors.torch import load_file
         from r3g.delight import InstructPix2Pix
-        pe = os.path.join(path, "prompt_embeds_empty.safetensors")
-        if not os.path.exists(pe):
-            raise FileNotFoundError("%s is missing: the CLIP text encoder is not on this path, the embedding of the empty prompt "
-                                    "is computed once with `python tools/make_prompt_embeds.py %s` (INTEGRATION.md)" % (pe, path))
-        prompt = load_file(pe)["prompt_embeds"]
-        prompt = prompt.reshape(1, prompt.shape[-2], prompt.shape[-1])
+        prompt = empty_prompt_embedding(path)
         vc = read_json(os.path.join(path, "vae", "config.json"))
         unet_config = unet_config_from_diffusers(read_json(os.path.join(path, "unet", "config.json")), prompt.shape[1])
         sched_cfg = read_json(os.path.join(path, "scheduler", "scheduler_config.json"), default={})

@@ -150,6 +150,11 @@ def shape_meshes(images, shapegen, config):
     return [shapegen(image=im, generator=torch.manual_seed(seed), **kw)[0] for im in images]
 
 
+# seconds of the two phases behind the shape model, per finished object of this process (the stage's report carries their means:
+# what a `-p 3` user waits for beyond the metric of bench.py -- SURVEY 8d excludes cleaners and texture from objects/sec)
+PHASE_SECONDS = {"cleaners": [], "texture": []}
+
+
 def finish_mesh(mesh, image, texgen, cleaners, config):
     """reference process_image :86-97: optional remesh, the three cleaners, the texture stage"""
     if mesh is None:
@@ -157,10 +162,15 @@ def finish_mesh(mesh, image, texgen, cleaners, config):
     if config.get("remesh", False):
         mesh = clean_and_validate_mesh(mesh, target_face_count=config.get("remesh_target_num_faces", 30000))
     print("Initial mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
+    t0 = time.time()
     for cleaner in cleaners:
         mesh = cleaner(mesh)
     print("Cleaned mesh has %d vertices and %d faces." % (mesh.n_vertices, mesh.n_faces))
-    return texgen(mesh, image=image)
+    t1 = time.time()
+    mesh = texgen(mesh, image=image)
+    PHASE_SECONDS["cleaners"].append(t1 - t0)
+    PHASE_SECONDS["texture"].append(time.time() - t1)
+    return mesh
 
 
 def generate_mesh(image, base, shapegen, texgen, cleaners, config):
@@ -463,6 +473,8 @@ def report(results, textured=True):
     rep = {"stage": "Hunyuan_2d_to_3d", "objects": len(results), "ok": ok,
            "failed": [os.path.basename(r[1]) for r in results if r[2] != "ok"],
            "seconds": [round(r[3], 3) for r in results],
+           "mean_seconds_cleaners": round(sum(PHASE_SECONDS["cleaners"]) / max(1, len(PHASE_SECONDS["cleaners"])), 3),
+           "mean_seconds_texture": round(sum(PHASE_SECONDS["texture"]) / max(1, len(PHASE_SECONDS["texture"])), 3),
            "textured": bool(textured)}
     if source:
         rep["texture_source"] = source

@@ -98,6 +98,11 @@ def test_configs1_literally_eight_crops_full_model(tmp_path):
     from parity_support import report
     report("configs[1] literal: stage script wall seconds for 8 crops (incl. model load)", wall, 1e9)
     report("configs[1] literal: mean seconds per object inside the stage", float(np.mean(rep["seconds"])), 1e9)
+    report("configs[1] literal:   of it the cleaners (1.2 M-face noise meshes -> 40 000 faces)", rep["mean_seconds_cleaners"], 1e9)
+    report("configs[1] literal:   of it the texture flow (both diffusion models, CI dims, 50 + 30 x 2 evaluations)",
+           rep["mean_seconds_texture"], 1e9)
+    report("configs[1] literal:   shape model + cleaners = what round 3 reported as the stage's seconds per object",
+           float(np.mean(rep["seconds"])) - rep["mean_seconds_texture"], 1e9)
 
 
 def test_octree_resolution_512_end_to_end():

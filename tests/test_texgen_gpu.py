@@ -133,7 +133,7 @@ def test_texture_stage_time_at_upstream_sizes():
     f = np.concatenate([f, f[:20480]])[:40960]          # 20 480 faces of the sphere + a second copy of them = 40 960 faces
     _, _, image = _scene(level=1, size=512)
     pipe = Hunyuan3DPaintPipeline()
-    assert pipe.texture_size == 2048 and pipe.render_size == 1024
+    assert pipe.texture_size == 2048 and pipe.render_size == 2048     # [UPSTREAM-RECALLED] Hunyuan3DTexGenConfig
     pipe(Mesh(v, f), image=image)                        # warm-up (workspace allocation)
     torch.cuda.synchronize()
     t0 = time.time()
