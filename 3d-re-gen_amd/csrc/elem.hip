@@ -32,17 +32,26 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 constexpr int LN_MAX_V4 = 8;  // up to C = 64*4*8 = 2048
 // four consecutive elements of a row held as f32 (XBF16 = false) or bf16 (true), as they sit in memory (the conversion of a prefetched row must not sit next to its load: it
 // would wait for the data at once)
-template <bool XBF16> struct Row4Raw { typedef float4 type; };
-template <> struct Row4Raw<true> { typedef uint2 type; };
-template <bool XBF16>
-__device__ __forceinline__ typename Row4Raw<XBF16>::type load_row4_raw(const float* base, int64_t elem) {
-    if constexpr (XBF16) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+// (XF: 0 f32 | 1 bf16 | 2 fp16 -- the DiT's 16-bit residual stream of round 4 is fp16, the reference's own activation type)
+struct Half4Raw { uint2 u; };
+template <int XF> struct Row4Raw { typedef float4 type; };
+template <> struct Row4Raw<1> { typedef uint2 type; };
+template <> struct Row4Raw<2> { typedef Half4Raw type; };
+template <int XF>
+__device__ __forceinline__ typename Row4Raw<XF>::type load_row4_raw(const float* base, int64_t elem) {
+    if constexpr (XF == 1) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    else if constexpr (XF == 2) return Half4Raw{*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem)};
     else return *reinterpret_cast<const float4*>(base + elem);
 }
 __device__ __forceinline__ float4 row4_cvt(const float4& r) { return r; }
 __device__ __forceinline__ float4 row4_cvt(const uint2& u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
                        __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ float4 row4_cvt(const Half4Raw& h) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = *reinterpret_cast<const h2*>(&h.u.x), b = *reinterpret_cast<const h2*>(&h.u.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
 }
 
 // One wave per row, the row held in registers.
@@ -55,7 +64,7 @@ __device__ __forceinline__ float4 row4_cvt(const uint2& u) {
 //   workgroup of 4 rows lives ~6 us however little it does (dispatch, kernarg fetch, exit), which at 131 072 rows per
 //   launch is as long as its memory time; 4 x RPW rows per workgroup amortise it.
 // The arithmetic per row (element -> lane map, order of every sum) is the same in all instantiations.
-template <bool XBF16, int NV, int RPW>
+template <int XBF16, int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     constexpr int NVC = NV ? NV : LN_MAX_V4;
     const int lane = threadIdx.x & 63;
@@ -583,11 +592,14 @@ hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.C % 64 || p.C > 2048) return hipErrorInvalidValue;
     ProfScope ps(PC_LAYERNORM, 6.0 * (double)p.rows * p.C, s);
     if (p.y8 && (p.C % 256 || (p.ldy8 & 3) || !p.y_scale)) return hipErrorInvalidValue;
-    if (p.x_bf16) {
+    if (p.x_bf16 == 2) {
         if (p.C % 256 || (p.ldx & 3) || (p.ldy & 3) || (p.x_batch_stride & 3)) return hipErrorInvalidValue;
-        R3G_LN_LAUNCH(true)
+        R3G_LN_LAUNCH(2)
+    } else if (p.x_bf16) {
+        if (p.C % 256 || (p.ldx & 3) || (p.ldy & 3) || (p.x_batch_stride & 3)) return hipErrorInvalidValue;
+        R3G_LN_LAUNCH(1)
     } else if (p.C % 256 == 0 && (p.ldx & 3) == 0 && (p.ldy & 3) == 0) {
-        R3G_LN_LAUNCH(false)
+        R3G_LN_LAUNCH(0)
     } else {
         hipLaunchKernelGGL(layernorm_small_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     }

@@ -365,7 +365,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         }
         return;
     }
-    if constexpr (EPI == EPI_RESID_BF16) {
+    if constexpr (EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16) {
+        constexpr bool F16 = EPI == EPI_RESID_F16;
         // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
         uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
         const uint16_t* XR = p.resid_src ? p.resid_src + (int64_t)batch * p.strideC : X;   // where the old values come from
@@ -419,9 +420,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     uint32_t q[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float lo = __uint_as_float(o[k] << 16), hi = __uint_as_float(o[k] & 0xFFFF0000u);
+                        const f32x2 ov = unpack16<F16>(o[k]);
                         const f32x4& d = k < 2 ? d0 : d1;
-                        q[k] = pack_bf16(lo + d[(k & 1) * 2], hi + d[(k & 1) * 2 + 1]);
+                        q[k] = pack16<F16>(ov[0] + d[(k & 1) * 2], ov[1] + d[(k & 1) * 2 + 1]);
                     }
                     if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
                 }
@@ -444,8 +445,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 const int n = ncol + j * 16, m = mrow + i * 16;
                 const f32x4 d = gj[j] * (acc[j][i] + bj[j]);
                 uint2 pk;
-                pk.x = pack_bf16(__uint_as_float(old[i].x << 16) + d[0], __uint_as_float(old[i].x & 0xFFFF0000u) + d[1]);
-                pk.y = pack_bf16(__uint_as_float(old[i].y << 16) + d[2], __uint_as_float(old[i].y & 0xFFFF0000u) + d[3]);
+                const f32x2 ox = unpack16<F16>(old[i].x), oy = unpack16<F16>(old[i].y);
+                pk.x = pack16<F16>(ox[0] + d[0], ox[1] + d[1]);
+                pk.y = pack16<F16>(oy[0] + d[2], oy[1] + d[3]);
                 if (n < p.N && m < p.M) *reinterpret_cast<uint2*>(X + (int64_t)m * p.ldc + n) = pk;
             }
         }
@@ -1767,7 +1769,7 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             else waves = 8;
         }
     }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_BF16 || EPI == EPI_BF16) {
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16 || EPI == EPI_BF16) {
         // deterministic split-K over 256x256 tiles (waves == 13 forces it): a deep K on a grid that fills less than half
         // of the CUs with 256x256 tiles and would otherwise run 128x128 tiles at 2.4x the operand traffic
         long tiles = (long)((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
@@ -1791,7 +1793,7 @@ hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
             // read-modify-write epilogues: bit 0 of gemm_persistent_resid admits the fp32 residual form, bit 1 the bf16 one
             // (round 4: the fused QKV epilogue runs in passes of 32 rows through the persistent kernel's 4 KiB of scratch per wave)
             const bool resid_ok = (EPI != EPI_RESID_F32 || (g_gemm_persistent_resid & 1)) &&
-                                  (EPI != EPI_RESID_BF16 || (g_gemm_persistent_resid & 2)) &&
+                                  ((EPI != EPI_RESID_BF16 && EPI != EPI_RESID_F16) || (g_gemm_persistent_resid & 2)) &&
                                   (EPI != EPI_QKV || (g_gemm_persistent_qkv && p.wide_epilogue));
             if (p.K >= 256 && (p2.M == 0 || p2.K >= 256) &&
                 (waves == 12 || (g_gemm_persistent && g_gemm_waves == 0 && tiles > g_num_cu && resid_ok && EPI != EPI_F32))) {
@@ -1867,7 +1869,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     // algorithmic bytes of a launch: each operand read once, the result written once (fp32 residual: read + written)
     auto alg_bytes = [](const GemmArgs& g) {
         if (g.M <= 0) return 0.0;
-        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 ? 4.0 : (g.epi == EPI_FP8_GELU_ERF ? 1.0 : 2.0));
+        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 || g.epi == EPI_RESID_F16 ? 4.0 : (g.epi == EPI_FP8_GELU_ERF ? 1.0 : 2.0));
         return (double)g.batch * (2.0 * g.M * g.K + out * (double)g.M * g.N) + 2.0 * (double)g.N * g.K;
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
@@ -1880,6 +1882,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
         case EPI_F32: return launch_epi<EPI_F32>(p, p2, g_gemm_glds, s);
         case EPI_QKV: return launch_epi<EPI_QKV>(p, p2, g_gemm_glds, s);
         case EPI_RESID_BF16: return launch_epi<EPI_RESID_BF16>(p, p2, g_gemm_glds, s);
+        case EPI_RESID_F16: return launch_epi<EPI_RESID_F16>(p, p2, g_gemm_glds, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -53,5 +53,26 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *reinterpret_cast<const uint32_t*>(&h);
 }
 
+// a 16-bit residual stream (EPI_RESID_BF16 / EPI_RESID_F16): two stream values of one 32-bit word as floats, and back (round
+// to nearest even both ways; the sum old + update is formed in fp32 by the caller and rounded ONCE here)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ f32x2 unpack16(uint32_t w) {
+    if constexpr (F16) {
+        return __builtin_convertvector(*reinterpret_cast<const f16x2*>(&w), f32x2);
+    } else {
+        return (f32x2){__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+    }
+}
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16(float a, float b) {
+    if constexpr (F16) {
+        const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+        return *reinterpret_cast<const uint32_t*>(&h);
+    } else {
+        return pack_bf16(a, b);
+    }
+}
+
 }  // namespace r3g
 #endif

@@ -16,6 +16,7 @@ enum GemmEpilogue {
     EPI_QKV = 5,             // split into attention operands: per-head q/k norm, Q/K [B][H][L][64], V^T [B][H][64][L]
     EPI_RESID_BF16 = 6,      // C(bf16) = bf16(C + gate[b][n] * (acc + bias)): a 16-bit residual stream (sum formed in fp32)
     EPI_FP8_GELU_ERF = 7,    // C(e4m3) = fp8(gelu_erf(acc + bias) * out_inv_scale): operand of a following fp8 GEMM (static scale)
+    EPI_RESID_F16 = 8,       // C(fp16) = fp16(C + gate[b][n] * (acc + bias)): the reference's own stream type (its pipelines run in fp16)
 };
 
 enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
@@ -66,7 +67,7 @@ struct GemmArgs {
     int64_t ldc, strideC;
     const float* gate;  // [batch][N] (strideGate, may be 0) or null
     int64_t strideGate;
-    const uint16_t* resid_src;   // EPI_RESID_BF16: the old values are read from here (same ldc / strideC) instead of from C; null: C
+    const uint16_t* resid_src;   // EPI_RESID_BF16 / EPI_RESID_F16: the old values are read from here (same ldc / strideC) instead of from C; null: C
     int M, N, K;        // K % 64 == 0, N % 4 == 0
     int epi;
     int batch;          // filled in by gemm_launch
@@ -140,8 +141,8 @@ void ln_set_fixed_count(bool on);     // 1 (default): compile-time element count
 // ------------------------------------------------------------------ elementwise / norms (elem.hip)
 // y(bf16)[r][c] = ((x - mean) * rstd * (w ? w[c] : 1) + (b ? b[c] : 0)) * (1 + scale[batch][c]) + shift[batch][c]
 struct LnArgs {
-    const float* x; int64_t ldx;        // f32 [rows][C] (bf16 [rows][C] behind the same pointer when x_bf16 != 0)
-    int x_bf16;
+    const float* x; int64_t ldx;        // f32 [rows][C] (16-bit [rows][C] behind the same pointer when x_bf16 != 0)
+    int x_bf16;                         // 0: f32 | 1: bf16 | 2: fp16
     uint16_t* y; int64_t ldy;           // bf16 [rows][C]
     uint8_t* y8; int64_t ldy8; float* y_scale;   // y8 != null: e4m3 [rows][C] + one scale per row INSTEAD of y (C % 256 == 0)
     int64_t x_batch_stride, y_batch_stride;  // row r lives at batch (r / rows_per_batch), local row r % rows_per_batch

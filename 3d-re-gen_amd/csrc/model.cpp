@@ -60,6 +60,7 @@ static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context a
 static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached intermediate results (Model::GeoCache) are tied to it
 static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
+static bool g_dit_resid_f16 = true;   // the DiT's residual stream of the de-duplicated CFG path in fp16 (the reference's activation type) instead of fp32
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
 // r3g_flow_sample runs steps [g_flow_first_step, g_flow_last_step) of its schedule (options "flow_first_step" / "flow_last_step";
 // default: all of them).  Consecutive segments of one schedule, each continuing on the previous one's latents, are the same
@@ -487,16 +488,26 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
     const int64_t catld = 5 * (int64_t)H;
     const int mh = c.dit_mlp_hidden;
     if (d.nb != NB) return fail(R3G_ERR_STATE, "dit batch arena not prepared for %d objects", NB);
+    // The residual stream: fp32, or (option "dit_resid_f16") fp16 -- the reference's own activation type (its pipelines run in
+    // fp16) -- in the same buffer: the read-modify-write epilogues of the N = 1024 projections and the LayerNorm reads move
+    // half the bytes.  `xrow(r)` = the stream from row r on, in either format.
+    const bool xh = g_dit_resid_f16 && H % 256 == 0;     // (the 16-bit LayerNorm input exists for whole 256-column rows: not CI dims)
+    const int xfmt = xh ? 2 : 0, epi_res = xh ? EPI_RESID_F16 : EPI_RESID_F32;
+    auto xrow = [&](int64_t r) -> void* {
+        return xh ? (void*)(reinterpret_cast<uint16_t*>(d.f32a) + r * H) : (void*)(d.f32a + r * H);
+    };
     Lin l;
     // inputs: every object's latents feed both of its CFG entries; cond rows + the single unconditional row per object
     R3G_TRY(cast_pad_launch(x_lat, c.dit_in_channels, d.inb, m.cin_pad, NB * Nl, c.dit_in_channels, m.cin_pad, 1.0f, s));
     R3G_RC(get_lin(m, "model.latent_in", true, &l));
+    // (fp16 stream: the stream starts as zeros and the two input projections ADD to it -- 0 + (acc + bias), rounded once)
+    if (xh) R3G_TRY(hipMemsetAsync(d.f32a, 0, (size_t)Rall * H * 2, s));
+    const int epi_in = xh ? EPI_RESID_F16 : EPI_F32;
     for (int j = 0; j < 2; ++j)
-        R3G_RC(gemm(d.inb, m.cin_pad, (int64_t)Nl * m.cin_pad, l, 0, H, d.f32a + (int64_t)j * Nl * H, H, 2LL * Nl * H, Nl, m.cin_pad,
-                    EPI_F32, nullptr, 0, NB, s));
+        R3G_RC(gemm(d.inb, m.cin_pad, (int64_t)Nl * m.cin_pad, l, 0, H, xrow((int64_t)j * Nl), H, 2LL * Nl * H, Nl, m.cin_pad,
+                    epi_in, nullptr, 0, NB, s));
     R3G_RC(get_lin(m, "model.cond_in", true, &l));
-    R3G_RC(gemm(d.ctx, c.dit_context_dim, 0, l, 0, H, d.f32a + (int64_t)TX0 * H, H, 0, Mtxt, c.dit_context_dim, EPI_F32,
-                nullptr, 0, 1, s));
+    R3G_RC(gemm(d.ctx, c.dit_context_dim, 0, l, 0, H, xrow(TX0), H, 0, Mtxt, c.dit_context_dim, epi_in, nullptr, 0, 1, s));
     R3G_TRY(timestep_embedding_launch(nullptr, t_scalar, 1, c.dit_time_factor, m.temb, s));
     R3G_RC(get_lin(m, "model.time_in.in_layer", true, &l));
     R3G_TRY(gemv_launch(m.temb, 1, 256, l.w, l.ldw, l.b, m.th, H, 0, 1, s));
@@ -548,18 +559,18 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
         return p;
     };
 
-    float* xt = d.f32a + (int64_t)TX0 * H;
+    void* const xt = xrow(TX0);
     uint16_t* xnt = d.xn + (int64_t)TX0 * H;
     uint16_t* catt = d.cat + (int64_t)TX0 * catld;
     // LayerNorm + modulation of both streams: one launch over all rows (the txt rows take their own scale / shift; pad
     // rows are normalised too and never read), or one launch per stream
     auto ln_streams = [&](const float* sc_i, const float* sh_i, const float* sc_t, const float* sh_t) -> int {
         if (!g_group_streams) {
-            R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, sc_i, sh_i, 0, 1e-6f, s));
-            return layernorm(xt, H, 0, xnt, H, 0, Mtxt, 1, H, nullptr, nullptr, sc_t, sh_t, 0, 1e-6f, s);
+            R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, sc_i, sh_i, 0, 1e-6f, s, xfmt));
+            return layernorm((const float*)xt, H, 0, xnt, H, 0, Mtxt, 1, H, nullptr, nullptr, sc_t, sh_t, 0, 1e-6f, s, xfmt);
         }
         LnArgs p{};
-        p.x = d.f32a; p.ldx = H; p.x_batch_stride = 0;
+        p.x = d.f32a; p.ldx = H; p.x_batch_stride = 0; p.x_bf16 = xfmt;
         p.y = d.xn; p.ldy = H; p.y_batch_stride = 0;
         p.scale = sc_i; p.shift = sh_i; p.mod_stride = 0;
         p.seg2_row0 = TX0; p.seg2_row1 = Rall; p.scale2 = sc_t; p.shift2 = sh_t;
@@ -588,8 +599,8 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
         // attention projection
         R3G_RC(get_lin(m, bi + "_attn.proj", true, &li));
         R3G_RC(get_lin(m, bt + "_attn.proj", true, &lt));
-        R3G_RC(gemm_pair(gemm_args(d.cat, catld, 0, li, 0, H, d.f32a, H, 0, TX0, H, EPI_RESID_F32, mi + 2 * H, 0), 1,
-                         gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Mtxt, H, EPI_RESID_F32, mt + 2 * H, 0), 1, s));
+        R3G_RC(gemm_pair(gemm_args(d.cat, catld, 0, li, 0, H, d.f32a, H, 0, TX0, H, epi_res, mi + 2 * H, 0), 1,
+                         gemm_args(catt, catld, 0, lt, 0, H, xt, H, 0, Mtxt, H, epi_res, mt + 2 * H, 0), 1, s));
         // MLP
         R3G_RC(ln_streams(mi + 4 * H, mi + 3 * H, mt + 4 * H, mt + 3 * H));
         R3G_RC(get_lin(m, bi + "_mlp.0", true, &li));
@@ -598,8 +609,8 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
                          gemm_args(xnt, H, 0, lt, 0, mh, catt + H, catld, 0, Mtxt, H, EPI_BF16_GELU_TANH, nullptr, 0), 1, s));
         R3G_RC(get_lin(m, bi + "_mlp.2", true, &li));
         R3G_RC(get_lin(m, bt + "_mlp.2", true, &lt));
-        R3G_RC(gemm_pair(gemm_args(d.cat + H, catld, 0, li, 0, H, d.f32a, H, 0, TX0, mh, EPI_RESID_F32, mi + 5 * H, 0), 1,
-                         gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Mtxt, mh, EPI_RESID_F32, mt + 5 * H, 0), 1, s));
+        R3G_RC(gemm_pair(gemm_args(d.cat + H, catld, 0, li, 0, H, d.f32a, H, 0, TX0, mh, epi_res, mi + 5 * H, 0), 1,
+                         gemm_args(catt + H, catld, 0, lt, 0, H, xt, H, 0, Mtxt, mh, epi_res, mt + 5 * H, 0), 1, s));
     }
     // Single blocks: linear1 = [qkv | mlp-in] over all rows.  The attention grid leaves part of the machine idle in its
     // last dispatch round; the MLP half of linear1 does not depend on the attention, so it CAN be issued on a second stream
@@ -615,7 +626,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
     for (int i = 0; i < c.dit_depth_single; ++i) {
         const std::string blk = fmt("model.single_blocks.%d", i);
         const float* mm = m.mod_all + m.mod_off[2 * c.dit_depth_double + i];
-        R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, Rall, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s));
+        R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, Rall, 1, H, nullptr, nullptr, mm + H, mm, 0, 1e-6f, s, xfmt));
         R3G_RC(get_lin(m, blk + ".linear1", true, &l));
         QkvSplitArgs q;
         R3G_RC(qkv_args(blk + ".norm.query_norm.scale", blk + ".norm.key_norm.scale", &q));
@@ -642,10 +653,10 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
         if (overlap) R3G_TRY(hipStreamWaitEvent(s, m.ev_join, 0));
         R3G_RC(get_lin(m, blk + ".linear2", true, &l));
-        R3G_RC(gemm(d.cat, catld, 0, l, 0, H, d.f32a, H, 0, Rall, H + mh, EPI_RESID_F32, mm + 2 * H, 0, 1, s));
+        R3G_RC(gemm(d.cat, catld, 0, l, 0, H, d.f32a, H, 0, Rall, H + mh, epi_res, mm + 2 * H, 0, 1, s));
     }
     const float* fm = m.mod_all + m.mod_off[2 * c.dit_depth_double + c.dit_depth_single];
-    R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, fm + H, fm, 0, 1e-6f, s));
+    R3G_RC(layernorm(d.f32a, H, 0, d.xn, H, 0, TX0, 1, H, nullptr, nullptr, fm + H, fm, 0, 1e-6f, s, xfmt));
     R3G_RC(get_lin(m, "model.final_layer.linear", true, &l));
     R3G_RC(gemm(d.xn, H, 0, l, 0, c.dit_in_channels, out2, c.dit_in_channels, 0, TX0, H, EPI_F32, nullptr, 0, 1, s));
     return R3G_OK;
@@ -1265,6 +1276,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "geo_q_cache")) g_geo_q_cache = value != 0;
     else if (!strcmp(name, "geo_q_cache_gb")) g_geo_q_cache_bytes = value < 0 ? -1 : (long long)value << 30;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
+    else if (!strcmp(name, "dit_resid_f16")) g_dit_resid_f16 = value != 0;
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;

@@ -397,7 +397,10 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * cached), "gemm_stream" (0 default | 1 | 2: bf16-output GEMMs with K >= 1024 on the 4-wave stream kernel of csrc/gemm4.hip where a
  * compute unit gets two tiles or more | wherever it applies; also gemm_waves = 14; bit-identical, measured slower than the
  * persistent phased kernel -- profiles/r04_gemm_stream.md), "gemm4_ablate" (timing-only masks for that kernel, results are
- * garbage), "gemm_early_wait" (0 default | 1: the persistent phased kernel waits for the next tile's first k-tile inside the bf16 epilogue, in
+ * garbage), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
+ * activation type -- | 0: in fp32, rounds 1-3; NOT bit-preserving: 50-step latents at full depth 3.3e-3 against 3.0e-3 from the
+ * fp32 oracle, tests/test_cfg1_golden_gpu.py; -21 ms per object),
+ * "gemm_early_wait" (0 default | 1: the persistent phased kernel waits for the next tile's first k-tile inside the bf16 epilogue, in
  * front of its first store, and enters the k-loop without waiting for the epilogue's store acknowledgements -- measured: no effect), "gemm_persistent_qkv" (0 default | 1: fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel,
  * their epilogue in passes of 32 rows -- measured 17 ms per object slower, profiles/r04_gemm_stream.md), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive
  * segments continuing on each other's latents are the same launches as one call -- how tests read the latents after 10, 20, ...

@@ -64,6 +64,15 @@ def run():
         grid = torch.zeros((n, n, n), dtype=torch.float32, device="cuda")
         pipe.model.grid_query(cfg["box_v"], R, out=grid, start=start, count=count)
         out["logits"] = grid.reshape(-1)[start:start + count].cpu()
+        # the same 50 steps with the DiT's residual stream in fp32 (option dit_resid_f16 = 0: rounds 1-3; the default since
+        # round 4 is fp16, the reference's own activation type)
+        try:
+            ffi.check(L.r3g_set_option(b"dit_resid_f16", 0))
+            lat32 = pipe.model.flow_sample(pipe.prepare_latents(torch.manual_seed(int(g["noise_seed"]))), cond2, steps, guidance,
+                                           cfg["sched"]["shift"], uncond_uniform=True)
+            out["lat_50_f32_stream"] = lat32.clone().cpu()
+        finally:
+            ffi.check(L.r3g_set_option(b"dit_resid_f16", 1))
     return out
 
 
@@ -102,3 +111,16 @@ def test_vae_and_grid_logits_at_full_depth(run):
     d = float((run["logits"] - lref).abs().max() / lref.abs().max())
     report("configs[1] full depth: 4096 grid logits of the 257^3 grid, max |d| / max |logit|", d, TOL["grid_logits"])
     assert d <= TOL["grid_logits"]
+
+
+def test_fp32_residual_stream_at_full_depth(run):
+    """option dit_resid_f16 = 0: the residual stream of the 48 blocks in fp32 (rounds 1-3) instead of fp16 (the default: what the
+    reference's fp16 pipeline holds) -- the same 50 steps against the same fp32 golden, and the two runs against each other"""
+    import torch
+    ref = torch.from_numpy(run["golden"]["lat_50"])
+    got = run["lat_50_f32_stream"]
+    assert torch.isfinite(got).all()
+    err = rel_l2(got, ref)
+    report("configs[1] full depth: latents after 50 steps with an fp32 residual stream (dit_resid_f16 = 0)", err, TOL["flow_sample_50"])
+    report("configs[1] full depth:   the fp16-stream run (default) against the fp32-stream run", rel_l2(run["lat_50"], got), TOL["flow_sample_50"])
+    assert err <= TOL["flow_sample_50"]
