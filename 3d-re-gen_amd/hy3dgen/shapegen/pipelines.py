@@ -143,7 +143,7 @@ class Hunyuan3DDiTPipeline:
 
     # ---- host side of an object, ahead of time -------------------------------------------------------
     # Everything an image needs before it meets the GPU (open / recentre / INTER_AREA resize / composite: ImageProcessorV2, then
-    # the conditioner's resize to 518 and normalisation) is ~14 ms of host work per crop.  A service that runs crop after crop
+    # the conditioner's resize to 518 and normalisation) is ~40 ms of host work per crop (measured on the GPU box).  A service that runs crop after crop
     # does it for the NEXT launch group on a host thread while the GPU is in the current group's 49 evaluations, instead of in
     # front of every group with the GPU idle: `prefetch(images)` starts it, the next `__call__` on the same image objects picks
     # the results up (any other call simply prepares its images itself).  Same functions, same results.
@@ -158,14 +158,27 @@ class Hunyuan3DDiTPipeline:
         """start the host-side preparation of `images` (the next call's objects) on a background thread"""
         import concurrent.futures
         if getattr(self, "_prefetch_pool", None) is None:
-            # one intra-op thread in the worker (omp_set_num_threads is per calling thread): with the default, the resize's
-            # parallel region started a full OpenMP team beside the HIP runtime's own threads and the main thread's launches
-            # stalled for hundreds of milliseconds per group
-            self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep",
-                                                                        initializer=torch.set_num_threads, initargs=(1,))
+            # torch's intra-op thread count is a PROCESS-WIDE setting (measured: set in one thread, read back in every other).
+            # With the default (all cores) the worker's antialiased resize started a full OpenMP team beside the HIP runtime's
+            # own threads and the main thread's launches stalled for hundreds of milliseconds per group: while a prefetch pool
+            # exists the process runs torch's host operators on ONE thread (they are the ~40 ms of one crop's preparation and
+            # the fp16 noise draw; nothing else of this path computes on the host).  `close_prefetch()` puts the caller's
+            # setting back; a host application that needs its own count calls torch.set_num_threads itself.
+            self._threads_before = torch.get_num_threads()
+            torch.set_num_threads(1)
+            self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep")
         images = list(images) if isinstance(images, (list, tuple)) else [images]
         self._prefetched = (tuple(id(im) for im in images), images,
                             [self._prefetch_pool.submit(self._host_prepare, im) for im in images])
+
+    def close_prefetch(self):
+        """stop the host-preparation thread and restore torch's intra-op thread count"""
+        pool = getattr(self, "_prefetch_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._prefetch_pool = None
+            self._prefetched = None
+            torch.set_num_threads(getattr(self, "_threads_before", torch.get_num_threads()))
 
     def _prepared(self, images):
         """the prepared conditioner inputs of `images`: from the prefetch when it was for exactly these objects"""

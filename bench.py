@@ -117,6 +117,7 @@ def cpu_baseline(cfg, steps, R, grid_np):
     """Oracle (PyTorch CPU fp32 restatement + C marching cubes) on a bounded sample, extrapolated to one object."""
     from oracle import hy3d_torch as H
     from oracle import mc as omc
+    torch.set_num_threads(os.cpu_count() or 1)      # every host core for the CPU baseline, whatever ran before
     torch.manual_seed(0)
     wide = H.wide_config(depth=1, depth_single=1, vae_layers=1, cond_layers=1)
     pipe = H.ShapePipeline(wide)
@@ -413,6 +414,8 @@ def main():
         except Exception as e:      # reporting only: never fails the bench line
             out.setdefault("roofline_mc", {})["object_like_field"] = {"error": str(e)}
     bad = False
+    if hasattr(pipe, "close_prefetch"):
+        pipe.close_prefetch()       # the host-preparation thread ends here; torch's thread count is the process's own again
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         oracle_mesh, out["cpu_baseline"] = cpu_baseline(cfg, S, R, last_grid.cpu().numpy())
         # the C oracle's mesh of the last TIMED object's grid against the mesh the timed region produced
