@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restri
     const int64_t total = (int64_t)Ho * Wo * 9 * c8n;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    x += (int64_t)blockIdx.y * H * W * C;                    // blockIdx.y = sample (round 4: all samples of a call in one launch)
+    out += (int64_t)blockIdx.y * Ho * Wo * 9 * C;
     const int c8 = (int)(i % c8n);
     const int64_t r = i / c8n;
     const int tap = (int)(r % 9);
@@ -55,10 +57,15 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restri
 // ---- GroupNorm, pass 1: block b sums rows [b*rpb, (b+1)*rpb) per channel (thread t owns channels t, t + 256, ...), folds
 // the channels of a group in LDS and writes (sum, sum of squares) per group as fp64 to partial[b][g][2]
 constexpr int GN_MAX_CPT = 12;   // channels per thread: C <= 3072 (the up blocks normalise cat(hidden, skip): 2560 channels)
+// Round 4: all samples of a call in ONE launch (blockIdx.y = sample; x and partial advance by a sample): the six views of the
+// multiview UNet used to be 6 x 2 launches of a few microseconds of work each -- GroupNorm was 39 % of the texture step's kernel
+// time (profiles/r04_texture_stage.md).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int C, int groups, int rpb,
                                                          double* __restrict__ partial) {
     __shared__ float s_sum[256 * GN_MAX_CPT], s_sq[256 * GN_MAX_CPT];
     const int t = threadIdx.x;
+    x += (int64_t)blockIdx.y * rows * C;
+    partial += (int64_t)blockIdx.y * gridDim.x * groups * 2;
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
     float a[GN_MAX_CPT], q[GN_MAX_CPT];
 #pragma unroll
@@ -86,27 +93,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-// ---- pass 2: every block first combines the partials of all groups (block order 0, 1, 2, ...: the same sum in every
-// block), then normalises its rows: y = ((x - mean) * rstd * gamma + beta) [-> SiLU] -> bf16, 4 channels per thread
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int rows, int C, int groups, int nblk,
-                                                       const double* __restrict__ partial, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int do_silu, int rpb,
+// ---- pass 2: one thread per (sample, group) combines the blocks' partials in block order 0, 1, 2, ... (fp64: the same sum
+// whatever the launch geometry) -> (mean, rstd).  Rounds 2-3 had EVERY block of pass 3 redo this sum: 256 blocks x 32 threads
+// x 256 dependent double loads in front of the normalisation.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const double* __restrict__ partial, int nblk, int groups, int rows, int cpg,
+                                                       float eps, float* __restrict__ stats) {
+    const int g = threadIdx.x, smp = blockIdx.x;
+    if (g >= groups) return;
+    const double* p = partial + (int64_t)smp * nblk * groups * 2;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += p[((int64_t)b * groups + g) * 2];
+        ss += p[((int64_t)b * groups + g) * 2 + 1];
+    }
+    const double n = (double)rows * cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;      // biased, as torch.nn.GroupNorm
+    if (var < 0.0) var = 0.0;
+    stats[((int64_t)smp * groups + g) * 2] = (float)mean;
+    stats[((int64_t)smp * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- pass 3: y = ((x - mean) * rstd * gamma + beta) [-> SiLU] -> bf16, 4 channels per thread
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int rows, int C, int groups,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int do_silu, int rpb,
                                                        uint16_t* __restrict__ y) {
     __shared__ float s_mean[256], s_rstd[256];
     const int t = threadIdx.x;
     const int cpg = C / groups;
-    for (int g = t; g < groups; g += 256) {
-        double s = 0.0, ss = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            s += partial[((int64_t)b * groups + g) * 2];
-            ss += partial[((int64_t)b * groups + g) * 2 + 1];
-        }
-        const double n = (double)rows * cpg;
-        const double mean = s / n;
-        double var = ss / n - mean * mean;      // biased, as torch.nn.GroupNorm
-        if (var < 0.0) var = 0.0;
-        s_mean[g] = (float)mean;
-        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    x += (int64_t)blockIdx.y * rows * C;
+    y += (int64_t)blockIdx.y * rows * C;
+    if (t < groups) {
+        s_mean[t] = stats[((int64_t)blockIdx.y * groups + t) * 2];
+        s_rstd[t] = stats[((int64_t)blockIdx.y * groups + t) * 2 + 1];
     }
     __syncthreads();
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
@@ -259,7 +279,7 @@ __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restr
 
 }  // namespace
 
-hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s) {
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s, int nb) {
     if (C % 8 || (stride != 1 && stride != 2) || (pad != 0 && pad != 1) || H < 1 || W < 1 || H + pad < 2 || W + pad < 2)
         return hipErrorInvalidValue;
     // zero padding: `pad` rows / columns before, one after (pad 1: the symmetric padding of the UNet's convolutions; pad 0: the
@@ -267,7 +287,7 @@ hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, 
     const int Ho = (H + pad + 1 - 3) / stride + 1, Wo = (W + pad + 1 - 3) / stride + 1;
     const int64_t total = (int64_t)Ho * Wo * 9 * (C / 8);
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, H, W, C, stride, pad, Ho, Wo, out);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256), nb < 1 ? 1 : nb), dim3(256), 0, s, x, H, W, C, stride, pad, Ho, Wo, out);
     return hipGetLastError();
 }
 
@@ -278,15 +298,18 @@ int group_norm_blocks(int rows) {
     return nblk;
 }
 
+// nb samples of `rows` rows each (contiguous); partial: workspace of nb * (group_norm_blocks(rows) * groups * 2 doubles + groups floats)
 hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
-                             int do_silu, uint16_t* y, double* partial, hipStream_t s) {
-    if (C % 4 || groups < 1 || groups > 256 || C % groups || C > 256 * GN_MAX_CPT || rows < 1) return hipErrorInvalidValue;
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb) {
+    if (C % 4 || groups < 1 || groups > 256 || C % groups || C > 256 * GN_MAX_CPT || rows < 1 || nb < 1) return hipErrorInvalidValue;
     const int nblk = group_norm_blocks(rows);
     const int rpb = (rows + nblk - 1) / nblk;
+    float* stats = reinterpret_cast<float*>(partial + (int64_t)nb * nblk * groups * 2);
     ProfScope prof_scope_(PC_LAYERNORM, 0.0, s);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C, groups, rpb, partial);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C, groups, nblk, (const double*)partial, gamma,
-                       beta, eps, do_silu, rpb, y);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, rpb, partial);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nb), dim3(256), 0, s, (const double*)partial, nblk, groups, rows, C / groups, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, (const float*)stats, gamma, beta,
+                       do_silu, rpb, y);
     return hipGetLastError();
 }
 

@@ -212,11 +212,12 @@ hipError_t f32_to_bf16_launch(const float* in, uint16_t* out, int64_t n, hipStre
 
 // ------------------------------------------------------------------ UNet blocks of the texture stage (conv_kernels.hip)
 // bf16 [H][W][C] -> bf16 [Ho*Wo][9 C] (column (ky*3 + kx)*C + c; zero padding 1; stride 1 | 2; C % 8 == 0)
-hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s);
-// GroupNorm (+ SiLU) of f32 rows [rows][C] -> bf16; partial: workspace of group_norm_blocks(rows) * groups * 2 doubles
+hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, int pad, uint16_t* out, hipStream_t s, int nb = 1);   // nb contiguous samples
+// GroupNorm (+ SiLU) of nb samples of f32 rows [nb][rows][C] -> bf16, every sample normalised on its own, all of them in three
+// launches; partial: workspace of nb * (group_norm_blocks(rows) * groups * 2 doubles + groups floats)
 int group_norm_blocks(int rows);
 hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
-                             int do_silu, uint16_t* y, double* partial, hipStream_t s);
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb = 1);
 // out(bf16)[r][c] = in[r][c] * gelu_erf(in[r][F + c])   (diffusers GEGLU)
 hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);

@@ -139,16 +139,14 @@ static int u_check_shape(const Unet& u, int H, int W, int C, const char* what, i
 static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int stride, const ULin& l, const float* bias, void* dst,
                      int epi, hipStream_t s, int pad = 1, int nb = 1) {
     const int Ho = (H + pad - 2) / stride + 1, Wo = (W + pad - 2) / stride + 1;
-    for (int n = 0; n < nb; ++n)
-        U_TRY(im2col3x3_launch(src + (int64_t)n * H * W * Cin, H, W, Cin, stride, pad, u.col + (int64_t)n * Ho * Wo * 9 * Cin, s));
+    U_TRY(im2col3x3_launch(src, H, W, Cin, stride, pad, u.col, s, nb));       // every sample of the call in one launch
     return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, nb * Ho * Wo, epi, s);
 }
 
 // GroupNorm (+ SiLU) per sample of f32 rows [nb][hw][C] -> bf16
 static int u_group_norm(Unet& u, const float* x, int hw, int C, const float* g, const float* b, float eps, int silu, uint16_t* y,
                         hipStream_t s, int nb = 1) {
-    for (int n = 0; n < nb; ++n)
-        U_TRY(group_norm_launch(x + (int64_t)n * hw * C, hw, C, u.c.groups, g, b, eps, silu, y + (int64_t)n * hw * C, u.gn_partial, s));
+    U_TRY(group_norm_launch(x, hw, C, u.c.groups, g, b, eps, silu, y, u.gn_partial, s, nb));     // all samples in one set of launches
     return R3G_OK;
 }
 
@@ -690,7 +688,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
                  o_q = carve(heads * hwp * 64 * 2), o_k = carve(heads * hwp * 64 * 2), o_v = carve(heads * hwp * 64 * 2),
                  o_att = carve(hw * C * 2), o_ff = carve(hw * 8 * C * 2), o_ff2 = carve(hw * 4 * C * 2),
                  o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
-                 o_gn = carve(256LL * 256 * 2 * 8), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
+                 o_gn = carve((int64_t)kMaxViews * (256LL * 256 * 2 * 8 + 256 * 2 * 4)), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
                  o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4), o_vecn = carve((int64_t)kMaxViews * C * 4),
                  o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4);
     hipError_t e = hipMalloc((void**)&u->arena, off);
