@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         for (int i = 0; i < NVC; ++i)
             if (NV || i < nv) bv[i] = *reinterpret_cast<const float4*>(p.b + (i * 64 + lane) * 4);
     }
+    float4 av[NVC], hv[NVC];
+    const float *sc_held = nullptr, *sh_held = nullptr;
 #pragma unroll 1
     for (int rr = 0; rr < RPW; ++rr, ++row) {
         const bool more = RPW > 1 && rr + 1 < RPW && row + 1 < p.rows;   // wave-uniform
@@ -104,17 +106,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave at a time)
         const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
         const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
-        float4 av[NVC], hv[NVC];
-        if (sc) {
+        // the modulation vectors are 8 bytes per element against the row's 2-4: a wave's consecutive rows nearly always
+        // share them (same object, same segment), so they stay in registers until the pointer changes (wave-uniform)
+        if (sc && sc != sc_held) {
 #pragma unroll
             for (int i = 0; i < NVC; ++i)
                 if (NV || i < nv) av[i] = *reinterpret_cast<const float4*>(sc + (i * 64 + lane) * 4);
         }
-        if (sh) {
+        if (sh && sh != sh_held) {
 #pragma unroll
             for (int i = 0; i < NVC; ++i)
                 if (NV || i < nv) hv[i] = *reinterpret_cast<const float4*>(sh + (i * 64 + lane) * 4);
         }
+        sc_held = sc;
+        sh_held = sh;
         if (more) load(row + 1);   // youngest loads of the iteration: the counted waits for the operands above leave them in flight
         float s = 0.f;
 #pragma unroll
@@ -585,7 +590,12 @@ static int g_ln_rows = 0;
 static bool g_ln_fixed = true;   // compile-time element counts for C = 1024 / 1536 (0: round 2's run-time count everywhere)
 void ln_set_fixed_count(bool on) { g_ln_fixed = on; }
 void ln_set_rows_per_wave(int rows) { g_ln_rows = rows == 1 || rows == 4 ? rows : 0; }
-static int ln_rows_per_wave(int rows) { return g_ln_rows ? g_ln_rows : (rows >= 4 * 4 * 4096 ? 4 : 1); }
+// 4 rows per wave from 65 536 rows per launch (the geo decoder's 131 072): below that, one row per wave.  Round 4 tried 4 rows
+// from 16 384 (a launch group's 30 060 modulated DiT rows, with the modulation vectors held across a wave's rows): LayerNorm
+// family 45.5 -> 46.8 ms per object, A/B twice on one box (profiles/r04_layernorm_rows.md) -- the option stays for the next try
+static int g_ln_rows4_min = 65536;
+void ln_set_rows4_min(int rows) { g_ln_rows4_min = rows > 0 ? rows : 65536; }
+static int ln_rows_per_wave(int rows) { return g_ln_rows ? g_ln_rows : (rows >= g_ln_rows4_min ? 4 : 1); }
 
 hipError_t layernorm_launch(const LnArgs& p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;

@@ -135,6 +135,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
 float attn_q_scale(float scale);
 void attn_set_wide_min(int items);     // generation 7: 256-query workgroups (generation 6) from this many work items on (default 2048)
 void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
+void ln_set_rows4_min(int rows);     // automatic rule: launches of at least this many rows take 4 rows per wave (65536)
 void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave
 void ln_set_fixed_count(bool on);     // 1 (default): compile-time element counts for C = 1024 / 1536
 

@@ -1300,6 +1300,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
     else if (!strcmp(name, "attn_wide_min")) attn_set_wide_min(value);
     else if (!strcmp(name, "ln_rows")) ln_set_rows_per_wave(value);
+    else if (!strcmp(name, "ln_rows4_min")) ln_set_rows4_min(value);
     else if (!strcmp(name, "ln_fixed")) ln_set_fixed_count(value != 0);
     else if (!strcmp(name, "floater_by_vertex")) mesh_set_floater_by_vertex(value != 0);
     else if (!strcmp(name, "mc_rows")) mc_set_rows_per_wave(value);

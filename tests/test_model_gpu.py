@@ -531,7 +531,7 @@ def test_full_width_conditioner_vae_and_grid_points(wide):
 
 def test_layernorm_instantiations_are_bit_identical(wide):
     """The row kernels (LayerNorm, ln_dot) exist with a compile-time or a run-time row length and with 1 or 4 rows per
-    wave (options ln_fixed / ln_rows; the automatic choice takes 4 rows only for >= 65 536 rows).  Same element -> lane
+    wave (options ln_fixed / ln_rows; the automatic choice takes 4 rows from 65 536 rows per launch, option ln_rows4_min).  Same element -> lane
     map, same order of every sum: conditioner (C = 1536), VAE (C = 1024, fp32 rows), geo decoder (bf16 rows, ln_dot, a
     row count that is not a multiple of 16) and a DiT step (modulated rows) must not change a bit."""
     import torch
