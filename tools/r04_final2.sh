@@ -12,5 +12,5 @@ cut -c1-600 gpurun_out/r04_bench.json; tail -2 gpurun_out/r04_bench.err
 R3G_BENCH_SHARE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 4 --warmup 4 --no-roofline > gpurun_out/r04_bench_2ranks_shared.json 2> gpurun_out/r04_bench_2ranks_shared.err
 cut -c1-400 gpurun_out/r04_bench_2ranks_shared.json; tail -2 gpurun_out/r04_bench_2ranks_shared.err
 bash tools/r04_tex_profile.sh
-timeout 1500 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -300 > gpurun_out/r04_final_tests.log
+timeout 720 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -300 > gpurun_out/r04_final_tests.log
 tail -4 gpurun_out/r04_final_tests.log
