@@ -113,11 +113,15 @@ def flops_per_object(cfg, steps, R):
     return 2 * steps * f_dit + f_vae + (R + 1) ** 3 * f_q
 
 
+HOST_THREADS = torch.get_num_threads()   # before any prefetch pool lowers it (256 hardware threads oversubscribe the fp32 oracle:
+                                         # the same sample took 96 s instead of 12 s, profiles/r04_bench_cpu256_threads.json)
+
+
 def cpu_baseline(cfg, steps, R, grid_np):
     """Oracle (PyTorch CPU fp32 restatement + C marching cubes) on a bounded sample, extrapolated to one object."""
     from oracle import hy3d_torch as H
     from oracle import mc as omc
-    torch.set_num_threads(os.cpu_count() or 1)      # every host core for the CPU baseline, whatever ran before
+    torch.set_num_threads(HOST_THREADS)             # torch's own choice for this host (its physical cores), whatever ran before
     torch.manual_seed(0)
     wide = H.wide_config(depth=1, depth_single=1, vae_layers=1, cond_layers=1)
     pipe = H.ShapePipeline(wide)
