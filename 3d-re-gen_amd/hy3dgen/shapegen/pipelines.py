@@ -101,8 +101,9 @@ class Hunyuan3DDiTPipeline:
     @classmethod
     def from_pretrained(cls, model_path, device="cuda", dtype=None, use_safetensors=True, variant="fp16",
                         subfolder="hunyuan3d-dit-v2-0", **kwargs):
-        """model_path: a local directory holding <subfolder>/config.yaml + model[.variant].safetensors
-        (the HF snapshot layout), or 'synthetic:<full|mini>[:seed]' for seeded synthetic weights."""
+        """model_path: a local directory holding <subfolder>/config.yaml + model[.variant].safetensors (or, with
+        use_safetensors=False or when no safetensors file is there, model[.variant].ckpt) -- the HF snapshot layout --, or
+        'synthetic:<full|mini>[:seed]' for seeded synthetic weights."""
         if isinstance(model_path, str) and model_path.startswith("synthetic:"):
             parts = model_path.split(":")
             cfg = builtin_config(parts[1])
@@ -114,14 +115,22 @@ class Hunyuan3DDiTPipeline:
                                     "directory or 'synthetic:full')" % path)
         with open(os.path.join(path, "config.yaml")) as f:
             cfg = config_from_yaml(yaml.safe_load(f))
-        return cls(cfg, _weights.load_safetensors_dir(path, variant), device, **kwargs)
+        return cls(cfg, _weights.load_safetensors_dir(path, variant, use_safetensors=use_safetensors), device, **kwargs)
 
     @classmethod
     def from_single_file(cls, ckpt_path, config_path, device="cuda", dtype=None, use_safetensors=None, **kwargs):
-        from safetensors.torch import load_file
+        """upstream's from_single_file: `ckpt_path` is a .safetensors file (flat, prefixed names) or a .ckpt torch pickle of
+        {"model", "vae", "conditioner"} state dicts; `use_safetensors` None = by the file's extension"""
         with open(config_path) as f:
             cfg = config_from_yaml(yaml.safe_load(f))
-        return cls(cfg, load_file(ckpt_path), device, **kwargs)
+        if use_safetensors is None:
+            use_safetensors = str(ckpt_path).endswith(".safetensors")
+        if use_safetensors:
+            from safetensors.torch import load_file
+            sd = load_file(ckpt_path)
+        else:
+            sd = _weights.flatten_ckpt(torch.load(ckpt_path, map_location="cpu", weights_only=True))
+        return cls(cfg, sd, device, **kwargs)
 
     def to(self, device=None, dtype=None):
         return self

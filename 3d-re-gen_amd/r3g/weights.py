@@ -143,13 +143,41 @@ def synthetic_state_dict(cfg, seed=0, device="cuda", std=None):
     return sd
 
 
-def load_safetensors_dir(path, variant=None):
-    """<path>/model[.variant].safetensors (upstream single-file layout with model./vae./conditioner. prefixes)."""
-    from safetensors.torch import load_file
-    names = ["model.%s.safetensors" % variant] if variant else []
-    names += ["model.safetensors", "model.fp16.safetensors"]
-    for n in names:
-        f = os.path.join(path, n)
+def load_safetensors_dir(path, variant=None, use_safetensors=True):
+    """<path>/model[.variant].safetensors (upstream single-file layout with model./vae./conditioner. prefixes), or -- upstream's
+    `use_safetensors=False` / older snapshots -- <path>/model[.variant].ckpt: a torch pickle of {"model": sd, "vae": sd,
+    "conditioner": sd} (loaded with weights_only=True), flattened to the same prefixed names.  [UPSTREAM-RECALLED: the two file
+    names and the three top-level keys are how hy3dgen/shapegen/pipelines.py `from_single_file` reads them.]"""
+    stems = (["model.%s" % variant] if variant else []) + ["model", "model.fp16"]
+    if use_safetensors:
+        from safetensors.torch import load_file
+        for n in stems:
+            f = os.path.join(path, n + ".safetensors")
+            if os.path.exists(f):
+                return load_file(f)
+    for n in stems:
+        f = os.path.join(path, n + ".ckpt")
         if os.path.exists(f):
-            return load_file(f)
-    raise FileNotFoundError("no model*.safetensors under " + path)
+            return flatten_ckpt(torch.load(f, map_location="cpu", weights_only=True))
+    raise FileNotFoundError("no model*.safetensors / model*.ckpt under " + path)
+
+
+def flatten_ckpt(ckpt):
+    """{"model": {...}, "vae": {...}, "conditioner": {...}} (optionally under "state_dict") -> {"model.x": t, ...}; a dict that
+    is already flat passes through"""
+    if isinstance(ckpt, dict) and isinstance(ckpt.get("state_dict"), dict):
+        ckpt = ckpt["state_dict"]
+    if not isinstance(ckpt, dict) or not ckpt:
+        raise ValueError("checkpoint is not a state dict")
+    if all(torch.is_tensor(v) for v in ckpt.values()):
+        return dict(ckpt)
+    flat = {}
+    for part, sd in ckpt.items():
+        if not isinstance(sd, dict):
+            continue          # e.g. a stored step counter
+        for k, v in sd.items():
+            if torch.is_tensor(v):
+                flat["%s.%s" % (part, k)] = v
+    if not flat:
+        raise ValueError("checkpoint holds no tensors under its top-level keys %s" % sorted(ckpt))
+    return flat

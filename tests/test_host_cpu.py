@@ -164,6 +164,23 @@ def test_snapshot_config_and_weight_files(tmp_path):
     assert set(W.load_safetensors_dir(str(tmp_path), None)) == set(sd)        # falls back to model.fp16.safetensors
     with pytest.raises(FileNotFoundError):
         W.load_safetensors_dir(str(tmp_path / "nope"), "fp16")
+    # upstream's other container: model[.variant].ckpt = a pickle of {"model", "vae", "conditioner"} state dicts
+    nested = {}
+    for k, v in sd.items():
+        part, rest = k.split(".", 1)
+        nested.setdefault(part, {})[rest] = v
+    assert set(nested) == {"model", "vae", "conditioner"}
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    torch.save(nested, str(ck / "model.fp16.ckpt"))
+    for kw in (dict(use_safetensors=False), dict()):              # asked for, or found because no safetensors file is there
+        back = W.load_safetensors_dir(str(ck), "fp16", **kw)
+        assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    with pytest.raises(FileNotFoundError):                         # use_safetensors=False does not fall back to safetensors
+        W.load_safetensors_dir(str(tmp_path), "fp16", use_safetensors=False)
+    assert set(W.flatten_ckpt({"state_dict": nested, "global_step": 7})) == set(sd) and W.flatten_ckpt(sd).keys() == sd.keys()
+    with pytest.raises(ValueError):
+        W.flatten_ckpt({"model": {"step": 3}})
 
 
 def test_bench_workload_definition():
