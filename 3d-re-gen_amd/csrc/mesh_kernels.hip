@@ -538,7 +538,7 @@ size_t mesh_workspace_bytes(int64_t nv, int64_t nf, int64_t max_cells) {
     addq(4 * (size_t)nv); addq(4 * (size_t)(nv + 1)); addq(12 * (size_t)nf); addq(80 * (size_t)nv); addq((size_t)nv);
     addq(4 * (size_t)nv); addq(8 * (size_t)nv); addq(4 * (size_t)nv); addq(8 * (size_t)nv); addq(4 * (size_t)nv);
     addq(4 * (size_t)nv); addq(4 * (size_t)m); addq(4 * (size_t)m); addq(12 * (size_t)nf); addq(12 * (size_t)nv);
-    addq(4 * (size_t)nv); addq(4 * scan_scratch_elems(3 * nf > m ? 3 * nf : m));
+    addq(4 * (size_t)nv); addq(8 * (size_t)nv); addq(4 * (size_t)nv); addq(4 * scan_scratch_elems(3 * nf > m ? 3 * nf : m));
     return (b > q ? b : q) + 4096;
 }
 
@@ -766,6 +766,8 @@ struct HipBackend {
     hipError_t err = hipSuccess;
     struct Atomics {
         __device__ static uint32_t inc(uint32_t* p) { return atomicAdd(p, 1u); }
+        __device__ static void min64(uint64_t* p, uint64_t v) { atomicMin((unsigned long long*)p, (unsigned long long)v); }
+        __device__ static void min32(int32_t* p, int32_t v) { atomicMin(p, v); }
     };
     void note(hipError_t e) { if (err == hipSuccess && e != hipSuccess) err = e; }
     template <class F>
@@ -814,6 +816,7 @@ hipError_t mesh_reduce_faces(char* ws, size_t ws_bytes, unsigned* h_small, float
     b.sel = ar.take<uint32_t>(nv); b.remap = ar.take<int32_t>(nv); b.keep = ar.take<uint32_t>(m);
     b.pos = ar.take<uint32_t>(m); b.faces_tmp = ar.take<int32_t>(3 * nf); b.verts_tmp = ar.take<float>(3 * nv);
     b.used = ar.take<uint32_t>(nv);
+    b.inkey = ar.take<uint64_t>(nv); b.inwho = ar.take<int32_t>(nv);
     be.bsum = ar.take<unsigned>((int64_t)scan_scratch_elems(3 * nf > m ? 3 * nf : m));
     if (ar.off > ws_bytes) return hipErrorOutOfMemory;
     const r3g_qem::Result r = r3g_qem::decimate(be, b, nv, nf, max_faces);

@@ -10,9 +10,9 @@
 // Parallel formulation: ROUNDS of independent collapses.  In a round
 //   1. every vertex picks its cheapest VALID incident edge (quadric error of the optimal position; valid = link
 //      condition, no normal flip of any surrounding face, boundary rules);
-//   2. an edge both of whose endpoints picked it is a candidate; a candidate survives if no other candidate with a
-//      smaller (cost, hash, id) key touches the one-ring of its endpoints, so surviving collapses have disjoint
-//      neighbourhoods and can be applied simultaneously with the validity they were checked for;
+//   2. every vertex PROPOSES its pick; a maximal set of proposals whose endpoints' closed one-rings are pairwise disjoint
+//      is selected, smallest (cost, hash, id) first (a few rounds of Luby's algorithm on that fixed order), so selected
+//      collapses can be applied simultaneously with the validity they were checked for;
 //   3. survivors are applied: the lower vertex id keeps the merged vertex (position = the optimum, quadric = sum), faces
 //      are re-indexed, collapsed faces dropped, the face list compacted in order.
 // Everything is a pure function of the input mesh: the vertex-face adjacency is sorted, quadrics are gathered in
@@ -228,54 +228,97 @@ R3G_QEM_HD int placement_mode(const MeshView& m, int v, int u) {
 }
 
 // ---- step 1: the cheapest valid edge at vertex v -> partner (or -1) and key
-R3G_QEM_HD void best_partner(const MeshView& m, int v, int32_t* partner, uint64_t* key) {
-    int32_t bp = -1;
-    uint64_t bk = kNoKey;
-    for (uint32_t i = m.off[v]; i < m.off[v + 1]; ++i) {
-        const int32_t* f = m.faces + 3 * m.adj[i];
-        for (int k = 0; k < 3; ++k) {
-            const int u = f[k];
-            if (u == v) continue;
-            // a neighbour shows up once per face around the edge (v, u): evaluate it for the first of them only (the ring's
-            // face indices are in cache; the evaluation gathers u's quadric and solves a 3x3 system)
-            bool dup = false;
-            for (uint32_t j = m.off[v]; j < i && !dup; ++j) {
-                const int32_t* g = m.faces + 3 * m.adj[j];
-                dup = g[0] == u || g[1] == u || g[2] == u;
-            }
-            if (dup) continue;
-            const int lo = v < u ? v : u, hi = v < u ? u : v;
-            // an interior vertex may merge INTO a boundary vertex (which stays put); two boundary vertices merge freely
-            // along a boundary edge (the constraint planes in their quadrics keep the outline), never across the interior
-            const int pin = placement_mode(m, v, u);
-            const Collapse c = edge_collapse(m, lo, hi, pin);
-            const uint64_t ky = edge_key(c.cost, lo, hi);
-            if (ky > bk || (ky == bk && u >= bp)) continue;          // not better than what we have: skip the checks
-            if (!link_condition(m, v, u)) continue;
-            if (!ring_keeps_orientation(m, v, u, c.pos) || !ring_keeps_orientation(m, u, v, c.pos)) continue;
-            bk = ky;
-            bp = u;
-        }
+// = the neighbour with the smallest (key, id) among those whose collapse passes the link condition and keeps both rings'
+// orientation.  The keys of all neighbours are cheap (the neighbour's quadric and a 3x3 system); the validity checks are
+// what costs (the link condition walks the rings of the ring).  So: keys first, then the checks in ascending key order
+// until one passes -- on a smooth mesh the first.  (Round 3 ran the checks whenever a neighbour improved on the best so
+// far, in adjacency order: H(n) ~ 2.5 times per vertex at valence 6.  Same result, by definition.)
+R3G_QEM_HD bool first_face_of_neighbour(const MeshView& m, int v, uint32_t i, int u) {
+    for (uint32_t j = m.off[v]; j < i; ++j) {
+        const int32_t* g = m.faces + 3 * m.adj[j];
+        if (g[0] == u || g[1] == u || g[2] == u) return false;
     }
-    *partner = bp;
-    *key = bk;
+    return true;
 }
 
-// ---- step 2: does the candidate edge (v, u), v < u, win against every other candidate in its neighbourhood?
-// mark_lo[w] = lower endpoint of the candidate edge w belongs to (-1: none), mark_key[w] its key
-R3G_QEM_HD bool candidate_wins(const MeshView& m, int v, int u, uint64_t key, const int32_t* mark_lo,
-                               const uint64_t* mark_key) {
-    const int ends[2] = {v, u};
+R3G_QEM_HD bool collapse_is_valid(const MeshView& m, int v, int u, D3 pos) {
+    return link_condition(m, v, u) && ring_keeps_orientation(m, v, u, pos) && ring_keeps_orientation(m, u, v, pos);
+}
+
+R3G_QEM_HD void best_partner(const MeshView& m, int v, int32_t* partner, uint64_t* key) {
+    // an interior vertex may merge INTO a boundary vertex (which stays put); two boundary vertices merge freely along a
+    // boundary edge (the constraint planes in their quadrics keep the outline), never across the interior: placement_mode
+    uint64_t floor_key = 0;      // candidates at or below (floor_key, floor_u) have been tried and were invalid
+    int32_t floor_u = -1;
+    for (;;) {
+        // the smallest (key, id) above the floor; nothing is stored per neighbour (a scan is a few gathers and a 3x3 system
+        // each; a list of keys would cost the kernel a third of its waves in registers)
+        int32_t bu = -1;
+        uint64_t bk = kNoKey;
+        for (uint32_t i = m.off[v]; i < m.off[v + 1]; ++i) {
+            const int32_t* f = m.faces + 3 * m.adj[i];
+            for (int k = 0; k < 3; ++k) {
+                const int u = f[k];
+                // a neighbour shows up once per face around the edge (v, u): take it at the first of them
+                if (u == v || !first_face_of_neighbour(m, v, i, u)) continue;
+                const int lo = v < u ? v : u, hi = v < u ? u : v;
+                const Collapse c = edge_collapse(m, lo, hi, placement_mode(m, v, u));
+                const uint64_t ky = edge_key(c.cost, lo, hi);
+                if (floor_u >= 0 && (ky < floor_key || (ky == floor_key && u <= floor_u))) continue;   // tried already
+                if (bu >= 0 && (ky > bk || (ky == bk && u >= bu))) continue;
+                bk = ky;
+                bu = u;
+            }
+        }
+        if (bu < 0) break;                                   // every neighbour tried
+        // (the position again: keeping it across the scan costs the kernel a wave per SIMD in registers)
+        const D3 bpos = edge_collapse(m, v < bu ? v : bu, v < bu ? bu : v, placement_mode(m, v, bu)).pos;
+        if (collapse_is_valid(m, v, bu, bpos)) {
+            *partner = bu;
+            *key = bk;
+            return;
+        }
+        floor_key = bk;
+        floor_u = bu;
+    }
+    *partner = -1;
+    *key = kNoKey;
+}
+
+// ---- step 2: the selection among the proposals (vertex c proposes the edge (c, partner[c])).
+// Order of proposals: (key, proposer id), total (a vertex proposes at most one edge).  Two proposals CONFLICT when an
+// endpoint of one lies in the closed one-ring of an endpoint of the other (adjacency is symmetric, so they see each other).
+// An iteration: undecided proposals that touch a `taken` vertex (an endpoint of a selected collapse) are out; of the rest,
+// those smaller than every conflicting undecided proposal are selected.  Selected collapses therefore have pairwise
+// disjoint closed neighbourhoods.  Proposals that END at a vertex w are seen through inkey / inwho[w], the smallest of them.
+constexpr int32_t kNoProposer = 0x7FFFFFFF;
+constexpr int kSelectIterations = 3;
+
+R3G_QEM_HD bool proposal_less(uint64_t ka, int32_t a, uint64_t kb, int32_t b) { return ka < kb || (ka == kb && a < b); }
+
+R3G_QEM_HD bool proposal_touches_taken(const MeshView& m, int c, int p, const uint32_t* taken) {
+    const int ends[2] = {c, p};
+    for (int s = 0; s < 2; ++s)
+        for (uint32_t i = m.off[ends[s]]; i < m.off[ends[s] + 1]; ++i) {
+            const int32_t* f = m.faces + 3 * m.adj[i];
+            if (taken[f[0]] | taken[f[1]] | taken[f[2]]) return true;
+        }
+    return false;
+}
+
+R3G_QEM_HD bool proposal_is_smallest(const MeshView& m, int c, const int32_t* partner, const uint64_t* key,
+                                     const uint32_t* state, const uint64_t* inkey, const int32_t* inwho) {
+    const int ends[2] = {c, partner[c]};
+    const uint64_t kc = key[c];
     for (int s = 0; s < 2; ++s) {
         const int a = ends[s];
         for (uint32_t i = m.off[a]; i < m.off[a + 1]; ++i) {
             const int32_t* f = m.faces + 3 * m.adj[i];
             for (int k = 0; k < 3; ++k) {
                 const int w = f[k];
-                const int32_t lo = mark_lo[w];
-                if (lo < 0 || lo == v) continue;
-                const uint64_t kw = mark_key[w];
-                if (kw < key || (kw == key && lo < v)) return false;
+                if (w != c && state[w] == 1u && proposal_less(key[w], w, kc, c)) return false;
+                const int32_t x = inwho[w];
+                if (x != kNoProposer && x != c && proposal_less(inkey[w], x, kc, c)) return false;
             }
         }
     }

@@ -27,7 +27,9 @@ struct Buffers {               // all sized for the INPUT mesh (nv vertices, nf 
     uint32_t* pos;             // [max(nv, nf)] scan result
     int32_t* faces_tmp;        // [nf][3]
     float* verts_tmp;          // [nv][3]
-    uint32_t* used;            // [nv]
+    uint32_t* used;            // [nv]     proposal state during a round's selection; vertex flags at the end
+    uint64_t* inkey;           // [nv]     smallest key among the undecided proposals that END at this vertex
+    int32_t* inwho;            // [nv]     ... and the smallest proposer id among those with that key
 };
 
 struct Result { int64_t nv, nf; int rounds; int64_t stalled_at; };
@@ -37,7 +39,8 @@ struct Result { int64_t nv, nf; int rounds; int64_t stalled_at; };
 //   uint32_t scan(const uint32_t* in, int64_t n, uint32_t* out)     exclusive scan, returns the total
 //   uint64_t sum_if(const uint32_t* w, const uint64_t* key, int64_t n, uint64_t thr)   sum of w[i] with w[i] && key[i] <= thr
 //   void zero(void* p, size_t bytes);  void copy(void* dst, const void* src, size_t bytes)
-//   static atomic_inc(uint32_t* p) -> old value                        (callable from inside parfor bodies)
+//   static Atomics::inc(uint32_t* p) -> old value, Atomics::min64(uint64_t*, uint64_t), Atomics::min32(int32_t*, int32_t)
+//                                                                       (callable from inside parfor bodies)
 template <class B>
 Result decimate(B& be, const Buffers& b, int64_t nv, int64_t nf, int64_t max_faces, int max_rounds = 400) {
     using AT = typename B::Atomics;
@@ -106,39 +109,68 @@ Result decimate(B& be, const Buffers& b, int64_t nv, int64_t nf, int64_t max_fac
     }
 
     while (nf > max_faces && res.rounds < max_rounds) {
-        // 1. cheapest valid edge per vertex
+        // 1. cheapest valid edge per vertex: vertex v PROPOSES the collapse (v, partner[v]).  The edge was checked from both
+        //    ends (link condition, both rings' orientation), so every proposal is a valid collapse of the mesh as it is now.
+        int32_t* partner = b.partner;
+        uint64_t* key = b.key;
+        int32_t* cand_hi = b.mark_lo;        // [lo] of a SELECTED collapse: its higher endpoint
+        uint64_t* cand_key = b.mark_key;     // [lo] its key (read by the budget threshold and the apply step)
+        uint32_t* sel = b.sel;
+        uint32_t* state = b.used;            // per proposer: 0 no proposal / out, 1 undecided
+        uint32_t* taken = b.keep;            // per vertex: endpoint of a selected collapse
+        uint32_t* verdict = b.pos;           // per proposer, one iteration: 1 selected now
+        uint64_t* inkey = b.inkey;
+        int32_t* inwho = b.inwho;
         {
-            int32_t* partner = b.partner;
-            uint64_t* key = b.key;
-            int32_t* mark_lo = b.mark_lo;
-            uint64_t* mark_key = b.mark_key;
-            uint32_t* sel = b.sel;
             int32_t* remap = b.remap;
             be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t v) {
                 best_partner(mv, (int)v, partner + v, key + v);
-                mark_lo[v] = -1;
-                mark_key[v] = kNoKey;
                 sel[v] = 0;
+                taken[v] = 0;
                 remap[v] = (int32_t)v;
             });
-            // 2a. mutual choices become candidates, marked at both endpoints
+            // an edge both of whose endpoints propose it is ONE proposal: the lower endpoint's
             be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t v) {
                 const int32_t u = partner[v];
-                if (u > v && partner[u] == (int32_t)v) {
-                    mark_lo[v] = (int32_t)v; mark_key[v] = key[v];
-                    mark_lo[u] = (int32_t)v; mark_key[u] = key[v];
-                }
+                state[v] = (u >= 0 && !(u < v && partner[u] == (int32_t)v)) ? 1u : 0u;
             });
-            // 2b. a candidate survives when it beats every other candidate around its endpoints
-            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t v) {
-                const int32_t u = partner[v];
-                if (u > v && mark_lo[v] == (int32_t)v && mark_lo[u] == (int32_t)v &&
-                    candidate_wins(mv, (int)v, u, key[v], mark_lo, mark_key))
-                    sel[v] = (uint32_t)shared_faces(mv, (int)v, u);
+        }
+        // 2. a maximal set of proposals with pairwise disjoint closed neighbourhoods, smallest (key, proposer) first: a
+        //    proposal is selected when no undecided proposal that touches the one-rings of its endpoints is smaller, and it is
+        //    out as soon as a selected one does (Luby's rounds on a fixed total order: the result is a pure function of the
+        //    mesh; three iterations reach the maximal set to within a round on the test meshes).  Proposals that END at a vertex w are seen through two atomic minima at w (key, then proposer id): taking
+        //    the minimum is order-independent.  Round 3 selected only MUTUAL choices that were local minima in one pass:
+        //    ~6 % of the faces per round, 52 rounds and 163 of 194 ms in step 1 on the bench's object; see
+        //    profiles/r04_cleaners_kernel_time.md.
+        for (int it = 0; it < kSelectIterations; ++it) {
+            if (it > 0)   // proposals next to a collapse selected in an earlier iteration are out
+                be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t c) {
+                    if (state[c] == 1u && proposal_touches_taken(mv, (int)c, partner[c], taken)) state[c] = 0u;
+                });
+            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t v) { inkey[v] = kNoKey; inwho[v] = kNoProposer; });
+            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t c) {
+                if (state[c] == 1u) AT::min64(&inkey[partner[c]], key[c]);
+            });
+            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t c) {
+                if (state[c] == 1u && inkey[partner[c]] == key[c]) AT::min32(&inwho[partner[c]], (int32_t)c);
+            });
+            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t c) {
+                verdict[c] = (state[c] == 1u && proposal_is_smallest(mv, (int)c, partner, key, state, inkey, inwho)) ? 1u : 0u;
+            });
+            be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t c) {
+                if (state[c] != 1u || !verdict[c]) return;
+                const int32_t p = partner[c];
+                const int32_t lo = (int32_t)c < p ? (int32_t)c : p, hi = (int32_t)c < p ? p : (int32_t)c;
+                sel[lo] = (uint32_t)shared_faces(mv, lo, hi);
+                cand_hi[lo] = hi;
+                cand_key[lo] = key[c];
+                taken[c] = 1u;
+                taken[p] = 1u;
+                state[c] = 0u;
             });
         }
         // 3. how many faces would go?  Keep the cheapest collapses only when the budget is nearly reached.
-        const uint64_t removable = be.sum_if(b.sel, b.key, nv, kNoKey);
+        const uint64_t removable = be.sum_if(b.sel, b.mark_key, nv, kNoKey);
         if (removable == 0) {
             // nothing can collapse under the current shape rules: relax them step by step (topology rules never)
             if (mv.relax < 2) { ++mv.relax; continue; }
@@ -151,20 +183,17 @@ Result decimate(B& be, const Buffers& b, int64_t nv, int64_t nf, int64_t max_fac
             uint64_t lo = 0, hi = kNoKey - 1;
             while (lo < hi) {
                 const uint64_t mid = lo + (hi - lo) / 2;
-                if (be.sum_if(b.sel, b.key, nv, mid) >= need) hi = mid; else lo = mid + 1;
+                if (be.sum_if(b.sel, b.mark_key, nv, mid) >= need) hi = mid; else lo = mid + 1;
             }
             thr = lo;
         }
         // 4. apply: the lower endpoint keeps the merged vertex
         {
-            const int32_t* partner = b.partner;
-            const uint64_t* key = b.key;
-            const uint32_t* sel = b.sel;
             int32_t* remap = b.remap;
             double* quad = b.quad;
             be.parfor(nv, [=] R3G_QEM_LAMBDA(int64_t v) {
-                if (!sel[v] || key[v] > thr) return;
-                const int u = partner[v];
+                if (!sel[v] || cand_key[v] > thr) return;
+                const int u = cand_hi[v];
                 const Collapse c = edge_collapse(mv, (int)v, u, placement_mode(mv, (int)v, u));
                 verts[3 * v] = (float)c.pos.x; verts[3 * v + 1] = (float)c.pos.y; verts[3 * v + 2] = (float)c.pos.z;
                 for (int k = 0; k < 10; ++k) quad[10 * v + k] += quad[10 * (int64_t)u + k];

@@ -16,6 +16,8 @@ namespace {
 struct HostBackend {
     struct Atomics {
         static uint32_t inc(uint32_t* p) { return (*p)++; }
+        static void min64(uint64_t* p, uint64_t v) { if (v < *p) *p = v; }
+        static void min32(int32_t* p, int32_t v) { if (v < *p) *p = v; }
     };
     template <class F>
     void parfor(int64_t n, F f) {
@@ -45,11 +47,12 @@ extern "C" int r3g_emu_qem(float* verts, int64_t* nv_io, int32_t* faces, int64_t
     std::vector<int32_t> adj(3 * nf), partner(nv), mark_lo(nv), remap(nv), faces_tmp(3 * nf);
     std::vector<double> quad(10 * nv);
     std::vector<uint8_t> bnd(nv);
-    std::vector<uint64_t> key(nv), mark_key(nv);
+    std::vector<uint64_t> key(nv), mark_key(nv), inkey(nv);
+    std::vector<int32_t> inwho(nv);
     std::vector<float> verts_tmp(3 * nv);
     r3g_qem::Buffers b{verts, faces, deg.data(), off.data(), adj.data(), quad.data(), bnd.data(), partner.data(), key.data(),
                        mark_lo.data(), mark_key.data(), sel.data(), remap.data(), keep.data(), pos.data(), faces_tmp.data(),
-                       verts_tmp.data(), used.data()};
+                       verts_tmp.data(), used.data(), inkey.data(), inwho.data()};
     HostBackend be;
     const r3g_qem::Result r = r3g_qem::decimate(be, b, nv, nf, max_faces);
     *nv_io = r.nv;
