@@ -315,6 +315,18 @@ def test_pipeline_takes_a_list_of_images():
     # ONE generator for the list: one draw of shape (n, N, C), upstream's prepare_latents
     one = pipe(image=imgs[:2], generator=torch.manual_seed(77), **kw)
     assert len(one) == 2 and all(m is not None and len(m.faces) > 0 for m in one)
+    # host preparation of the call's images ahead of time on a thread (what the stage script and bench.py do for the NEXT
+    # launch group): the same meshes, and torch's thread count is the caller's again afterwards
+    threads = torch.get_num_threads()
+    try:
+        pipe.prefetch(imgs)
+        ahead = pipe(image=imgs, generator=[torch.Generator().manual_seed(77) for _ in imgs], **kw)
+        assert pipe._prefetched is None                       # picked up by that call
+    finally:
+        pipe.close_prefetch()
+    assert torch.get_num_threads() == threads
+    for a, b in zip(many, ahead):
+        assert np.array_equal(a.faces, b.faces) and np.array_equal(a.vertices, b.vertices)
 
 
 def test_vae_and_grid_query(tiny):

@@ -1,0 +1,85 @@
+"""Host preparation of the NEXT launch group on a thread (hy3dgen/shapegen/pipelines.py: prefetch / _prepared /
+close_prefetch; used by stage/run.py and bench.py so that a crop's ~40 ms of host work runs under the previous group's GPU
+loop).  The host side needs no GPU: the pipeline object is built around a stub model."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "3d-re-gen_amd"))
+
+
+class _StubModel:
+    num_latents, in_channels = 8, 4
+
+
+def _pipeline():
+    import hy3dgen.shapegen.pipelines as pl
+
+    class P(pl.Hunyuan3DDiTFlowMatchingPipeline):
+        def _make_model(self, cfg, state_dict, grid_chunk):
+            return _StubModel()
+    cfg = pl.builtin_config("full")
+    cfg["cond"]["image_size"] = 70
+    return P(cfg, {}, "cuda:0")
+
+
+def _crop(seed):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    a = np.zeros((96, 80, 4), np.uint8)
+    a[20:70, 10:60, :3] = rng.integers(0, 255, (50, 50, 3))
+    a[20:70, 10:60, 3] = 255
+    return Image.fromarray(a, "RGBA")
+
+
+def test_prefetched_inputs_equal_the_direct_ones_and_run_on_the_worker_thread():
+    p = _pipeline()
+    imgs = [_crop(0), _crop(1), _crop(2)]
+    direct = [p._host_prepare(im) for im in imgs]
+    assert all(d.shape == (3, 70, 70) and d.dtype == torch.float32 for d in direct)
+    seen = []
+    orig = p._host_prepare
+    p._host_prepare = lambda im: (seen.append(threading.current_thread().name), orig(im))[1]
+    before = torch.get_num_threads()
+    try:
+        p.prefetch(imgs)
+        assert torch.get_num_threads() == 1                  # process-wide while the pool exists (see prefetch())
+        got = p._prepared(imgs)                              # the same image OBJECTS: picked up from the worker
+        assert all(torch.equal(a, b) for a, b in zip(got, direct))
+        assert len(seen) == 3 and all(n.startswith("r3g-host-prep") for n in seen)
+        assert p._prefetched is None                         # consumed
+        # a call on other objects (here: equal pixels, different objects) prepares them itself, on this thread
+        seen.clear()
+        p.prefetch(imgs)
+        other = [im.copy() for im in imgs[:2]]
+        got2 = p._prepared(other)
+        assert all(torch.equal(a, b) for a, b in zip(got2, direct[:2]))
+        assert seen.count(threading.current_thread().name) == 2
+        # a second prefetch replaces the first; a single image is a group of one
+        p.prefetch(imgs[2])
+        assert torch.equal(p._prepared([imgs[2]])[0], direct[2])
+    finally:
+        p.close_prefetch()
+    assert torch.get_num_threads() == before and p._prefetch_pool is None
+    p.close_prefetch()                                       # idempotent
+    assert p.timings["host_prepare_s"] > 0.0
+
+
+def test_a_crop_that_cannot_be_prepared_raises_at_pick_up():
+    from PIL import Image
+    p = _pipeline()
+    bad = Image.fromarray(np.zeros((16, 16, 4), np.uint8), "RGBA")      # fully transparent: nothing to recentre on
+    with pytest.raises(Exception) as direct:
+        p._host_prepare(bad)
+    try:
+        p.prefetch([_crop(3), bad])
+        with pytest.raises(type(direct.value)):
+            p._prepared(p._prefetched[1])
+    finally:
+        p.close_prefetch()
