@@ -143,6 +143,23 @@ class WorkQueue:
             first = int(self.store.add(self.key, k)) - k
         return list(range(first, min(first + k, self.n)))
 
+    def remaining(self):
+        """how many indices nobody has claimed yet (a snapshot: other ranks keep claiming)"""
+        taken = self._local if self.store is None else int(self.store.add(self.key, 0))
+        return max(0, self.n - taken)
+
+    def claim_guided(self, k_max, world=None):
+        """Guided self-scheduling: claim min(k_max, ceil(remaining / world)) indices (at least one).  With many objects left
+        every claim is a full launch group of k_max; when the list runs short the claims shrink so that every rank still gets
+        some -- 8 crops on 8 GPUs are one object per rank, not two ranks with four each and six idle ones."""
+        if world is None:
+            world = dist.get_world_size() if self.store is not None else 1
+        return self.claim_many(guided_claim_size(self.remaining(), k_max, world))
+
+
+def guided_claim_size(remaining, k_max, world):
+    return max(1, min(int(k_max), -(-int(remaining) // max(1, int(world)))))
+
 
 def exchange_json(obj, name="r3g_exchange", dst=None):
     """every rank contributes one JSON-serialisable object; rank `dst` (None: every rank) gets the list of all of them

@@ -297,6 +297,8 @@ def run_rank(config, image_paths, output_folder, rank, world, factory, swallow_e
     for item in pending:
         _collect_export(item, results, image_paths, rank, swallow_errors)
     writer.shutdown()
+    if hasattr(shapegen, "close_prefetch"):
+        shapegen.close_prefetch()
     results.sort(key=lambda r: r[0])
     return results, texture_state(texgen)
 
@@ -342,18 +344,32 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
     B = objects_per_launch(config)
     mine, status = [], []
     rank_error = None
-    texgen = None
+    shapegen = texgen = None
     claimed = []
     try:
         shapegen, texgen, cleaners = factory(config, device)
-        while True:
-            claimed = queue.claim_many(B)
-            if not claimed:
-                break
-            images = [Image.fromarray(crops[i].cpu().numpy(), "RGBA") for i in claimed]
-            bases = [_stem(image_paths[i]) for i in claimed]
+
+        def images_of(idx):
+            return [Image.fromarray(crops[i].cpu().numpy(), "RGBA") for i in idx]
+        # Claims are guided (a full launch group while the list is long, smaller ones when it runs short: every rank gets
+        # work) and, while every rank can still get a full group, one group AHEAD: while a group is on the GPU the next one
+        # is already claimed and its crops are prepared on the pipeline's host thread (prefetch), as in the one-process path;
+        # near the end of the list a rank claims only when it is free, so that nobody sits on objects an idle GPU could take.
+        # `claimed` holds everything this rank has taken and not reported yet -- a rank-level failure reports all of it.
+        claimed = queue.claim_guided(B, world)
+        ahead_images = None
+        while claimed:
+            current = list(claimed)
+            images = ahead_images if ahead_images is not None else images_of(current)
+            nxt = queue.claim_guided(B, world) if queue.remaining() >= B * world else []
+            claimed = current + nxt
+            ahead_images = None
+            if nxt and hasattr(shapegen, "prefetch"):
+                ahead_images = images_of(nxt)
+                shapegen.prefetch(ahead_images)
+            bases = [_stem(image_paths[i]) for i in current]
             # one object failing must not fail the stage (reference :135-136 swallows it silently)
-            for i, base, (mesh, err, secs) in zip(claimed, bases, generate_group(images, bases, shapegen, texgen, cleaners,
+            for i, base, (mesh, err, secs) in zip(current, bases, generate_group(images, bases, shapegen, texgen, cleaners,
                                                                                   config, isolate=True)):
                 if err is None:
                     if stream_out:
@@ -364,7 +380,7 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
                 else:
                     print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
                     status.append((i, image_paths[i], "error: %s" % err, secs, rank))
-            claimed = []
+            claimed = nxt if nxt else queue.claim_guided(B, world)
     except Exception as e:      # rank-level failure: keep what is finished, report what was in flight, stay collective
         rank_error = e
         print("ERROR on rank %d (rank-level, outside the per-object handling): %r" % (rank, e), file=sys.stderr)
@@ -372,6 +388,8 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
         for i in claimed:
             if i not in done:
                 status.append((i, image_paths[i], "error: rank %d failed: %s" % (rank, e), 0.0, rank))
+    if shapegen is not None and hasattr(shapegen, "close_prefetch"):
+        shapegen.close_prefetch()
     ok_flags = rdist.all_ok(rank_error is None)
     failed_ranks = [r for r, ok in enumerate(ok_flags) if not ok]
     local = []

@@ -83,3 +83,28 @@ def test_a_crop_that_cannot_be_prepared_raises_at_pick_up():
             p._prepared(p._prefetched[1])
     finally:
         p.close_prefetch()
+
+
+def test_guided_claim_sizes():
+    """r3g.dist.guided_claim_size / WorkQueue.claim_guided: full launch groups while the list is long, smaller claims when it
+    runs short -- BASELINE.json configs[1] (8 crops) on 8 GPUs is one object per rank, not two ranks with four each"""
+    from r3g import dist as rdist
+    g = rdist.guided_claim_size
+    assert g(8, 4, 8) == 1 and g(64, 4, 8) == 4 and g(20, 4, 8) == 3 and g(9, 4, 8) == 2 and g(1, 4, 8) == 1
+    assert g(0, 4, 8) == 1 and g(5, 4, 1) == 4 and g(3, 4, 1) == 3          # (claim_many clips an empty list to [])
+    # a queue without a process group: one "rank", groups of 4 then the rest
+    q = rdist.WorkQueue(10)
+    assert q.remaining() == 10
+    assert q.claim_guided(4) == [0, 1, 2, 3] and q.claim_guided(4) == [4, 5, 6, 7] and q.claim_guided(4) == [8, 9]
+    assert q.remaining() == 0 and q.claim_guided(4) == []
+    # eight ranks taking turns on 8 objects: everybody gets one; on 40 objects the first claims are full groups
+    q = rdist.WorkQueue(8)
+    assert [q.claim_guided(4, world=8) for _ in range(8)] == [[i] for i in range(8)]
+    q = rdist.WorkQueue(40)
+    sizes = []
+    while True:
+        c = q.claim_guided(4, world=8)
+        if not c:
+            break
+        sizes.append(len(c))
+    assert sizes[:3] == [4, 4, 4] and sizes[-1] == 1 and sum(sizes) == 40 and sorted(sizes, reverse=True) == sizes
