@@ -362,3 +362,60 @@ def test_work_queues_of_the_same_name_start_fresh(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29680", str(drv)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "QUEUES_OK" in r.stdout, r.stdout + r.stderr
+
+
+def prefetching_factory(config, device):
+    """content_factory with the real pipeline's list call, prefetch / close_prefetch (recorded per rank in a log file)"""
+    s, t, c = batch_factory(config, device)
+    log = os.path.join(os.path.dirname(config["prepped_for_hunyuan"]), "prefetch_rank%s.log" % os.environ.get("RANK", "0"))
+
+    class Ahead(type(s)):
+        def prefetch(self, images):
+            self._ahead = [id(im) for im in images]
+            open(log, "a").write("prefetch %d\n" % len(images))
+
+        def close_prefetch(self):
+            open(log, "a").write("close\n")
+
+        def __call__(self, image=None, **kw):
+            ims = image if isinstance(image, (list, tuple)) else [image]
+            hit = getattr(self, "_ahead", None) == [id(im) for im in ims]
+            if hit:                                   # (as the pipeline: a call on other objects leaves the prefetch alone)
+                self._ahead = None
+            open(log, "a").write("call %d %s\n" % (len(ims), "prepared-ahead" if hit else "cold"))
+            return super().__call__(image=image, **kw)
+    return Ahead(), t, c
+
+
+def test_ranks_claim_ahead_and_prefetch_while_work_is_plentiful(tmp_path):
+    """two ranks, 21 objects, groups of 4: while at least 4 x world objects are unclaimed a rank claims one group ahead and
+    hands exactly those image objects to the pipeline's prefetch; near the end it claims only when free; same files as the
+    one-rank run; the prefetch pool is closed on every rank"""
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 21)
+    _run_ranks(tmp_path, cfg, 1, 0, "content_factory")
+    one = _glbs(out)
+    r = _run_ranks(tmp_path, cfg, 2, 29681, "prefetching_factory")
+    assert _glbs(out) == one and len(one) == 21
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["ok"] == 21
+    calls = 0
+    for rank in (0, 1):
+        lines = open(tmp_path / ("prefetch_rank%d.log" % rank)).read().split("\n")
+        lines = [l for l in lines if l]
+        assert lines[-1] == "close" and lines.count("close") == 1
+        assert lines[0].startswith("prefetch") or lines[0].startswith("call")
+        ahead = [l for l in lines if l.endswith("prepared-ahead")]
+        assert len(ahead) == lines.count("prefetch 4") and len(ahead) >= 1       # every prefetched group was picked up
+        calls += sum(int(l.split()[1]) for l in lines if l.startswith("call"))
+    assert calls == 21
+
+
+def test_eight_crops_on_eight_ranks_are_one_object_each(tmp_path):
+    """BASELINE.json configs[1] (1 scene / 8 crops) on an 8-GPU node: guided claims hand out single objects, so the work
+    spreads over the ranks instead of two ranks taking four objects each"""
+    cfg, inp, out, names = make_distinct_scene(tmp_path, 8)
+    r = _run_ranks(tmp_path, cfg, 8, 29690, "batch_factory")
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
+    assert rep["objects"] == 8 and rep["ok"] == 8
+    per_rank = {k: rep["rank_of_object"].count(k) for k in set(rep["rank_of_object"])}
+    assert len(per_rank) >= 4 and max(per_rank.values()) <= 3, per_rank     # (instant stand-ins: a fast rank may come back twice)
