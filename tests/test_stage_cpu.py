@@ -410,12 +410,26 @@ def test_ranks_claim_ahead_and_prefetch_while_work_is_plentiful(tmp_path):
     assert calls == 21
 
 
+def slow_batch_factory(config, device):
+    """batch_factory whose calls take half a second (a rank that is on an object cannot come back for the next one at once)"""
+    import time
+    s, t, c = batch_factory(config, device)
+
+    class Slow(type(s)):
+        def __call__(self, image=None, **kw):
+            time.sleep(0.5)
+            return super().__call__(image=image, **kw)
+    return Slow(), t, c
+
+
 def test_eight_crops_on_eight_ranks_are_one_object_each(tmp_path):
     """BASELINE.json configs[1] (1 scene / 8 crops) on an 8-GPU node: guided claims hand out single objects, so the work
     spreads over the ranks instead of two ranks taking four objects each"""
     cfg, inp, out, names = make_distinct_scene(tmp_path, 8)
-    r = _run_ranks(tmp_path, cfg, 8, 29690, "batch_factory")
+    r = _run_ranks(tmp_path, cfg, 8, 29690, "slow_batch_factory")
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
     assert rep["objects"] == 8 and rep["ok"] == 8
     per_rank = {k: rep["rank_of_object"].count(k) for k in set(rep["rank_of_object"])}
-    assert len(per_rank) >= 4 and max(per_rank.values()) <= 3, per_rank     # (instant stand-ins: a fast rank may come back twice)
+    # the ranks leave the queue's constructor together (a barrier) and an object takes 0.5 s: nobody gets a second one while
+    # others have none -- unless a rank is more than half a second late on a loaded machine, hence the slack
+    assert len(per_rank) >= 6 and max(per_rank.values()) <= 2, per_rank
