@@ -398,16 +398,18 @@ def test_ranks_claim_ahead_and_prefetch_while_work_is_plentiful(tmp_path):
     assert _glbs(out) == one and len(one) == 21
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"stage"')][-1])
     assert rep["ok"] == 21
-    calls = 0
+    calls = picked_up = 0
     for rank in (0, 1):
         lines = open(tmp_path / ("prefetch_rank%d.log" % rank)).read().split("\n")
         lines = [l for l in lines if l]
         assert lines[-1] == "close" and lines.count("close") == 1
         assert lines[0].startswith("prefetch") or lines[0].startswith("call")
         ahead = [l for l in lines if l.endswith("prepared-ahead")]
-        assert len(ahead) == lines.count("prefetch 4") and len(ahead) >= 1       # every prefetched group was picked up
+        # every prefetched group is a full one (claims ahead only happen while >= 4 x world objects are left) and was picked up
+        assert len(ahead) == lines.count("prefetch 4") == sum(l.startswith("prefetch") for l in lines)
+        picked_up += len(ahead)
         calls += sum(int(l.split()[1]) for l in lines if l.startswith("call"))
-    assert calls == 21
+    assert calls == 21 and picked_up >= 1       # (which rank claims ahead how often depends on who gets to the counter first)
 
 
 def slow_batch_factory(config, device):
