@@ -1733,18 +1733,10 @@ int g_gemm_persistent_resid = 0;   // experiment switch (r3g_set_option "gemm_pe
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
-int g_gemm_stream = 0;   // gemm4.hip: 0 off | 1 where a compute unit gets at least two tiles | 2 wherever the kernel applies
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStream_t s) {
-    // bf16 outputs with a short K: the 4-wave stream kernel (gemm_waves == 14 forces it where it applies)
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) {
-        if (g_gemm_waves == 14 || (g_gemm_waves == 0 && g_gemm_stream > 0)) {
-            const hipError_t e = launch_gemm4(p, p2, g_num_cu, g_gemm_waves == 14 || g_gemm_stream > 1, s);
-            if (e != hipErrorNotSupported) return e;
-        }
-    }
-    int waves = g_gemm_waves == 14 ? 0 : g_gemm_waves;
+    int waves = g_gemm_waves;
     const int batch = p.batch;
     if (waves == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.md): 256x256 tiles (16 waves, half the L2->LDS traffic per
@@ -1828,9 +1820,8 @@ void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
 void gemm_set_early_wait(bool on) { g_gemm_early_wait = on; }
 void gemm_set_persistent_qkv(bool on) { g_gemm_persistent_qkv = on; }
-void gemm_set_stream(int mode) { g_gemm_stream = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void gemm_set_config(int waves) {
-    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 14 || waves == 16 || waves == 32) g_gemm_waves = waves;
+    if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;
 }
 
 static bool gemm_args_ok(const GemmArgs& p) {

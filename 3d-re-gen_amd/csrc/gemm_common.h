@@ -1,4 +1,4 @@
-// gemm_common.h -- arithmetic shared by every GEMM kernel (gemm.hip, gemm4.hip): the epilogue functions must be the same
+// gemm_common.h -- arithmetic shared by every GEMM kernel (gemm.hip; round 4's stream kernel, now tools/ubench/gemm4_stream.hip): the epilogue functions must be the same
 // code in all of them, because the kernels are interchangeable per launch and their results are compared bit for bit.
 #ifndef R3G_GEMM_COMMON_H
 #define R3G_GEMM_COMMON_H

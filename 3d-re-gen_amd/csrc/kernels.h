@@ -87,12 +87,8 @@ void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off b
 void gemm_set_config(int waves);   // tile kernel: 0 automatic | 4 | 8 | 9 | 10 | 11 | 12 | 13 | 16 | 32 (include/r3g.h)
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
-void gemm4_set_ablate(int mask);      // gemm4.hip timing experiments (results are wrong with any bit set)
 void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default off: measured slower)
 void gemm_set_early_wait(bool on);   // persistent phased kernel: the next tile's first k-tile is waited for inside the epilogue (default off: no effect)
-void gemm_set_stream(int mode);      // gemm4.hip stream kernel for bf16 outputs: 0 off | 1 from two tiles per compute unit | 2 always
-// gemm4.hip: hipErrorNotSupported when the launch is outside what the stream kernel covers
-hipError_t launch_gemm4(const GemmArgs& p, const GemmArgs& p2, int num_cu, bool force, hipStream_t s);
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs
 void gemm_set_persistent_resid(int mask);   // persistent form also for the fp32 (bit 0) / bf16 (bit 1) residual epilogues
 void gemm_set_persistent(bool on);   // phased kernel walks several tiles per workgroup (default on)

@@ -1289,12 +1289,10 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_persistent")) gemm_set_persistent(value != 0);
     else if (!strcmp(name, "gemm_persistent_resid")) gemm_set_persistent_resid(value);
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
-    else if (!strcmp(name, "gemm_stream")) gemm_set_stream(value);
     else if (!strcmp(name, "gemm_early_wait")) gemm_set_early_wait(value != 0);
     else if (!strcmp(name, "gemm_persistent_qkv")) gemm_set_persistent_qkv(value != 0);
     else if (!strcmp(name, "flow_first_step")) g_flow_first_step = value;
     else if (!strcmp(name, "flow_last_step")) g_flow_last_step = value < 0 ? (1 << 30) : value;
-    else if (!strcmp(name, "gemm4_ablate")) gemm4_set_ablate(value);
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);

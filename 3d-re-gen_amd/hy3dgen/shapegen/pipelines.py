@@ -152,49 +152,69 @@ class Hunyuan3DDiTPipeline:
 
     # ---- host side of an object, ahead of time -------------------------------------------------------
     # Everything an image needs before it meets the GPU (open / recentre / INTER_AREA resize / composite: ImageProcessorV2, then
-    # the conditioner's resize to 518 and normalisation) is ~40 ms of host work per crop (measured on the GPU box).  A service that runs crop after crop
-    # does it for the NEXT launch group on a host thread while the GPU is in the current group's 49 evaluations, instead of in
-    # front of every group with the GPU idle: `prefetch(images)` starts it, the next `__call__` on the same image objects picks
-    # the results up (any other call simply prepares its images itself).  Same functions, same results.
+    # the conditioner's resize to 518 and normalisation) is ~15-40 ms of host work per crop (measured on the GPU box).  A service
+    # that runs crop after crop does it for the NEXT launch group on a host thread while the GPU is in the current group's 49
+    # evaluations, instead of in front of every group with the GPU idle: `prefetch(images)` starts it, the `__call__` on the same
+    # image objects picks the results up (any other call simply prepares its images itself).  Same functions, same results.
+    # Round 5: (a) several groups may be pending at once, keyed by the identity of their image objects -- the callers issue
+    # prefetch(next group) BEFORE they run the current one, and round 4's single slot was overwritten by exactly that call, so
+    # that only a run's last group was ever picked up (every other crop was prepared twice: ADVICE r4); (b) the host path runs no
+    # torch operator any more (preprocessors.py: numpy / scipy.sparse / PIL, all single-threaded), so the pool no longer touches
+    # torch's process-wide intra-op thread count; (c) the timing sum is updated under a lock.
+    _PREFETCH_MAX_GROUPS = 4
+
     def _host_prepare(self, image):
         import time
         t0 = time.perf_counter()
         x = conditioner_transform(self.prepare_image(image)["image"], self.cfg["cond"]["image_size"])[0]
-        self.timings["host_prepare_s"] = self.timings.get("host_prepare_s", 0.0) + time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        with self._timings_lock():
+            self.timings["host_prepare_s"] = self.timings.get("host_prepare_s", 0.0) + dt
+            self.timings["host_prepare_n"] = self.timings.get("host_prepare_n", 0) + 1
         return x
 
+    def _timings_lock(self):
+        lock = self.__dict__.get("_tlock")
+        if lock is None:
+            import threading
+            lock = self.__dict__.setdefault("_tlock", threading.Lock())
+        return lock
+
     def prefetch(self, images):
-        """start the host-side preparation of `images` (the next call's objects) on a background thread"""
+        """start the host-side preparation of `images` (a coming call's objects) on a background thread; the call that is
+        made with these same image objects picks the results up.  Up to _PREFETCH_MAX_GROUPS groups may be pending."""
         import concurrent.futures
         if getattr(self, "_prefetch_pool", None) is None:
-            # torch's intra-op thread count is a PROCESS-WIDE setting (measured: set in one thread, read back in every other).
-            # With the default (all cores) the worker's antialiased resize started a full OpenMP team beside the HIP runtime's
-            # own threads and the main thread's launches stalled for hundreds of milliseconds per group: while a prefetch pool
-            # exists the process runs torch's host operators on ONE thread (they are the ~40 ms of one crop's preparation and
-            # the fp16 noise draw; nothing else of this path computes on the host).  `close_prefetch()` puts the caller's
-            # setting back; a host application that needs its own count calls torch.set_num_threads itself.
-            self._threads_before = torch.get_num_threads()
-            torch.set_num_threads(1)
             self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep")
+            self._prefetched = {}
         images = list(images) if isinstance(images, (list, tuple)) else [images]
-        self._prefetched = (tuple(id(im) for im in images), images,
-                            [self._prefetch_pool.submit(self._host_prepare, im) for im in images])
+        key = tuple(id(im) for im in images)
+        if key in self._prefetched:
+            return
+        while len(self._prefetched) >= self._PREFETCH_MAX_GROUPS:       # a group nobody came for: the oldest goes
+            _, (_, futs) = next(iter(self._prefetched.items()))
+            for f in futs:
+                f.cancel()
+            del self._prefetched[next(iter(self._prefetched))]
+        self._prefetched[key] = (images, [self._prefetch_pool.submit(self._host_prepare, im) for im in images])
 
     def close_prefetch(self):
-        """stop the host-preparation thread and restore torch's intra-op thread count"""
+        """stop the host-preparation thread (pending groups are dropped)"""
         pool = getattr(self, "_prefetch_pool", None)
         if pool is not None:
             pool.shutdown(wait=True)
             self._prefetch_pool = None
-            self._prefetched = None
-            torch.set_num_threads(getattr(self, "_threads_before", torch.get_num_threads()))
+            self._prefetched = {}
 
     def _prepared(self, images):
-        """the prepared conditioner inputs of `images`: from the prefetch when it was for exactly these objects"""
+        """the prepared conditioner inputs of `images`: from a prefetch when one was made for exactly these objects"""
         pending = getattr(self, "_prefetched", None)
-        if pending is not None and pending[0] == tuple(id(im) for im in images):
-            self._prefetched = None
-            return [f.result() for f in pending[2]]
+        if pending:
+            hit = pending.pop(tuple(id(im) for im in images), None)
+            if hit is not None:
+                with self._timings_lock():
+                    self.timings["prefetch_hits"] = self.timings.get("prefetch_hits", 0) + len(images)
+                return [f.result() for f in hit[1]]
         return [self._host_prepare(im) for im in images]
 
     def prepare_latents(self, generator):

@@ -84,8 +84,11 @@ def resize_area_u8(arr, w, h):
 
 
 def array_to_tensor(np_array):
-    t = torch.tensor(np.ascontiguousarray(np_array)).float() / 255 * 2 - 1
-    return t.permute(2, 0, 1)[None].contiguous()
+    """uint8 [H][W][C] -> float32 [1][C][H][W] in [-1, 1].  numpy arithmetic (the same IEEE operations, in the same order, as
+    upstream's `torch.tensor(a).float() / 255 * 2 - 1`: bit-identical), so that the host-preparation thread runs no torch
+    operator -- torch's intra-op thread pool is process-wide (pipelines.py: prefetch)"""
+    a = np.asarray(np_array).astype(np.float32) / np.float32(255) * np.float32(2) - np.float32(1)
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)[None]))
 
 
 class ImageProcessorV2:
@@ -142,17 +145,54 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+def _aa_bilinear_operator(n_in, n_out):
+    """One axis of torch's F.interpolate(mode="bilinear", antialias=True, align_corners=False) (aten
+    _upsample_bilinear2d_aa: the triangle filter, stretched by the scale when the axis shrinks, weights normalised per output
+    sample; float32 throughout, as aten computes them for float32 input) as a sparse [n_out][n_in] float32 operator.
+    Checked against the real operator, shrinking and enlarging: tests/test_preprocess_cpu.py."""
+    from scipy.sparse import csr_matrix
+    f32 = np.float32
+    scale = f32(n_in) / f32(n_out)
+    support = scale if scale >= 1 else f32(1)
+    inv = f32(1) / scale if scale >= 1 else f32(1)
+    i = np.arange(n_out, dtype=np.float32)
+    center = scale * (i + f32(0.5))
+    xmin = np.maximum((center - support + f32(0.5)).astype(np.int64), 0)
+    xsize = np.minimum((center + support + f32(0.5)).astype(np.int64), n_in) - xmin
+    taps = int(xsize.max())
+    j = np.arange(taps, dtype=np.int64)[None, :]
+    x = ((j + xmin[:, None]).astype(np.float32) - center[:, None] + f32(0.5)) * inv
+    w = np.maximum(f32(1) - np.abs(x), f32(0)).astype(np.float32)
+    w[j >= xsize[:, None]] = 0
+    tot = w.sum(axis=1, dtype=np.float32)
+    w = np.where(tot[:, None] != 0, w / np.where(tot == 0, f32(1), tot)[:, None], w).astype(np.float32)
+    col = j + xmin[:, None]
+    keep = j < xsize[:, None]
+    rows = np.repeat(np.arange(n_out), taps).reshape(n_out, taps)
+    return csr_matrix((w[keep], (rows[keep], col[keep])), shape=(n_out, n_in), dtype=np.float32)
+
+
+def resize_bilinear_aa(x, nh, nw):
+    """float32 [C][H][W] -> [C][nh][nw]: the width pass first, then the height pass (aten's order)"""
+    C, H, W = x.shape
+    t = (_aa_bilinear_operator(W, nw) @ np.ascontiguousarray(x.reshape(C * H, W).T)).T.reshape(C, H, nw)     # [C][H][nw]
+    t = _aa_bilinear_operator(H, nh) @ np.ascontiguousarray(t.transpose(1, 0, 2)).reshape(H, C * nw)          # [nh][C nw]
+    return np.ascontiguousarray(t.reshape(nh, C, nw).transpose(1, 0, 2)).astype(np.float32, copy=False)
+
+
 def conditioner_transform(image, image_size, value_range=(-1, 1)):
     """conditioner.ImageEncoder.forward up to the model call: map to [0,1], torchvision
-    Resize(image_size, BILINEAR, antialias=True) + CenterCrop(image_size) + Normalize.  [B,3,H,W] -> same."""
+    Resize(image_size, BILINEAR, antialias=True) + CenterCrop(image_size) + Normalize.  [B,3,H,W] -> same.
+    Host work in numpy / scipy.sparse (round 5): the thread that prepares the next launch group must not start torch's
+    process-wide intra-op thread team beside the HIP runtime (pipelines.py: prefetch), so no torch operator computes here."""
     low, high = value_range
-    x = (image.float() - low) / (high - low)
+    a = image.detach().cpu().numpy() if isinstance(image, torch.Tensor) else np.asarray(image)
+    x = (a.astype(np.float32) - np.float32(low)) / np.float32(high - low)
     _, _, h, w = x.shape
     s = image_size / min(h, w)
     nh, nw = (image_size, int(w * s)) if h <= w else (int(h * s), image_size)   # torchvision Resize truncates
-    x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
     top, left = (nh - image_size) // 2, (nw - image_size) // 2
-    x = x[:, :, top:top + image_size, left:left + image_size]
-    mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
-    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
-    return ((x - mean) / std).contiguous()
+    mean = np.asarray(IMAGENET_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(IMAGENET_STD, np.float32).reshape(3, 1, 1)
+    out = np.stack([(resize_bilinear_aa(xb, nh, nw)[:, top:top + image_size, left:left + image_size] - mean) / std for xb in x])
+    return torch.from_numpy(np.ascontiguousarray(out.astype(np.float32, copy=False)))

@@ -117,11 +117,13 @@ class WorkQueue:
     collective; every instance counts from zero under a key of its own (name + construction sequence number), so a second
     queue of the same name in the same process group starts fresh."""
 
-    def __init__(self, n_items, name="r3g_queue"):
+    def __init__(self, n_items, name="r3g_queue", use_store=None):
+        """use_store: None = the store when there is more than one rank, a local counter otherwise; True = the store whenever a
+        process group exists (a one-rank group then runs exactly the code of a node: tests/test_nccl_one_rank_gpu.py)"""
         self.n = int(n_items)
         self.store = None
         self._local = 0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or use_store):
             self.store = side_store()
             self.key = _next_key(name)
             if dist.get_rank() == 0:

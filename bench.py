@@ -113,7 +113,7 @@ def flops_per_object(cfg, steps, R):
     return 2 * steps * f_dit + f_vae + (R + 1) ** 3 * f_q
 
 
-HOST_THREADS = torch.get_num_threads()   # before any prefetch pool lowers it (256 hardware threads oversubscribe the fp32 oracle:
+HOST_THREADS = torch.get_num_threads()   # (256 hardware threads oversubscribe the fp32 oracle:
                                          # the same sample took 96 s instead of 12 s, profiles/r04_bench_cpu256_threads.json)
 
 
@@ -205,9 +205,15 @@ def main():
     if world > 1:   # the host-side preprocess of every rank shares the box's cores
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     dist = None
-    if world > 1:
+    # the multi-rank path (crops broadcast from rank 0, meshes gathered to it, the strong block's queue) whenever the process was
+    # started by torch.distributed.run -- also at WORLD_SIZE = 1 (round 5): the launch line the driver uses for N = 8 then runs
+    # the same code on an RCCL group of one.  A plain `python bench.py` (the driver's N = 1 invocation) has no launcher
+    # environment and stays the one-process path.
+    launched = "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("R3G_BENCH_FORCE_DIST") == "1"
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -292,7 +298,7 @@ def main():
         # strong scaling: a FIXED total of 8 crops per GPU of the node (configs[2]: 8 scenes x 8 objects on 8 GPUs), claimed
         # dynamically B at a time (r3g.dist.WorkQueue), meshes gathered -- enough objects per rank for the queue to balance
         total_s = 8 * world
-        q = rdist.WorkQueue(total_s, name="bench_strong")
+        q = rdist.WorkQueue(total_s, name="bench_strong", use_store=True)
         barrier()
         t1 = time.perf_counter()
         mine = []
@@ -324,7 +330,8 @@ def main():
                                       "%d flow-matching steps x CFG 2, %d^3 grid query + Lewiner marching cubes"
                                       % (a.steps, a.model, S, R + 1),
                           "weights": "seeded synthetic", "objects_total": total, "objects_per_launch": B,
-                          "parallelism": "object-parallel x%d" % world},
+                          "parallelism": "object-parallel x%d" % world,
+                          "process_group": None if dist is None else dist.get_backend()},
                "flops_per_object": flops_per_object(cfg, S, R),
                "mesh_last": None if last is None else {"V": int(last[0].shape[0]), "F": int(last[1].shape[0])}}
         # upstream's algorithmic FLOPs over the measured time.  The kernels EXECUTE about 9 % fewer FLOPs
@@ -419,7 +426,7 @@ def main():
             out.setdefault("roofline_mc", {})["object_like_field"] = {"error": str(e)}
     bad = False
     if hasattr(pipe, "close_prefetch"):
-        pipe.close_prefetch()       # the host-preparation thread ends here; torch's thread count is the process's own again
+        pipe.close_prefetch()       # the host-preparation thread ends here
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         oracle_mesh, out["cpu_baseline"] = cpu_baseline(cfg, S, R, last_grid.cpu().numpy())
         # the C oracle's mesh of the last TIMED object's grid against the mesh the timed region produced
@@ -433,7 +440,10 @@ def main():
             out["mc_parity"] = "exact" if same else "MISMATCH"
             bad = not same
     if rank == 0:
-        out["host_prepare_ms_per_object"] = 1000.0 * pipe.timings.get("host_prepare_s", 0.0) / max(1, n_local)
+        # host side of a crop: mean milliseconds per preparation, and how many of the run's crops were picked up from the
+        # host thread instead of being prepared in front of their launch group (round 5: all but the very first group's)
+        out["host_prepare_ms_per_object"] = 1000.0 * pipe.timings.get("host_prepare_s", 0.0) / max(1, pipe.timings.get("host_prepare_n", n_local))
+        out["host_prepared_ahead"] = "%d of %d" % (pipe.timings.get("prefetch_hits", 0), pipe.timings.get("host_prepare_n", 0))
         print(json.dumps(out))
     if bad:
         raise SystemExit("bench.py: the timed object's mesh differs from the marching-cubes oracle's mesh of the same grid")

@@ -394,10 +394,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
  * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "geo_q_cache_gb" (the
  * budget of geo_q_cache in GiB; < 0, the default: 30 % of the device's memory; a grid that needs more gets a prefix of its passes
- * cached), "gemm_stream" (0 default | 1 | 2: bf16-output GEMMs with K >= 1024 on the 4-wave stream kernel of csrc/gemm4.hip where a
- * compute unit gets two tiles or more | wherever it applies; also gemm_waves = 14; bit-identical, measured slower than the
- * persistent phased kernel -- profiles/r04_gemm_stream.md), "gemm4_ablate" (timing-only masks for that kernel, results are
- * garbage), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
+ * cached), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
  * activation type -- | 0: in fp32, rounds 1-3; NOT bit-preserving: 50-step latents at full depth 3.3e-3 against 3.0e-3 from the
  * fp32 oracle, tests/test_cfg1_golden_gpu.py; -21 ms per object),
  * "gemm_early_wait" (0 default | 1: the persistent phased kernel waits for the next tile's first k-tile inside the bf16 epilogue, in

@@ -25,3 +25,16 @@ if os.environ.get("R3G_TEST_CPU_SHIM") == "1":
     sys.path.insert(0, os.path.dirname(here))
     import ref_shim
     ref_shim.install()
+
+if os.environ.get("R3G_TEST_REPORT_MAPS") == "1":
+    # the GPU twin of the reference-script test asks the UNMODIFIED script's interpreter which native libraries it ended up with
+    import atexit
+
+    def _report_maps():
+        try:
+            with open("/proc/self/maps") as f:
+                libs = sorted({ln.split("/")[-1].strip() for ln in f if "libr3g" in ln})
+        except OSError:
+            libs = []
+        print("[test stub] native libraries mapped at exit: %s" % (", ".join(libs) or "none"), flush=True)
+    atexit.register(_report_maps)

@@ -316,12 +316,12 @@ def test_pipeline_takes_a_list_of_images():
     one = pipe(image=imgs[:2], generator=torch.manual_seed(77), **kw)
     assert len(one) == 2 and all(m is not None and len(m.faces) > 0 for m in one)
     # host preparation of the call's images ahead of time on a thread (what the stage script and bench.py do for the NEXT
-    # launch group): the same meshes, and torch's thread count is the caller's again afterwards
+    # launch group): the same meshes, and torch's thread count is never touched
     threads = torch.get_num_threads()
     try:
         pipe.prefetch(imgs)
         ahead = pipe(image=imgs, generator=[torch.Generator().manual_seed(77) for _ in imgs], **kw)
-        assert pipe._prefetched is None                       # picked up by that call
+        assert pipe._prefetched == {}                         # picked up by that call
     finally:
         pipe.close_prefetch()
     assert torch.get_num_threads() == threads

@@ -49,11 +49,12 @@ def test_prefetched_inputs_equal_the_direct_ones_and_run_on_the_worker_thread():
     before = torch.get_num_threads()
     try:
         p.prefetch(imgs)
-        assert torch.get_num_threads() == 1                  # process-wide while the pool exists (see prefetch())
+        # round 5: the pool leaves torch's process-wide intra-op thread count alone (the host path runs no torch operator)
+        assert torch.get_num_threads() == before
         got = p._prepared(imgs)                              # the same image OBJECTS: picked up from the worker
         assert all(torch.equal(a, b) for a, b in zip(got, direct))
         assert len(seen) == 3 and all(n.startswith("r3g-host-prep") for n in seen)
-        assert p._prefetched is None                         # consumed
+        assert p._prefetched == {}                           # consumed
         # a call on other objects (here: equal pixels, different objects) prepares them itself, on this thread
         seen.clear()
         p.prefetch(imgs)
@@ -61,14 +62,51 @@ def test_prefetched_inputs_equal_the_direct_ones_and_run_on_the_worker_thread():
         got2 = p._prepared(other)
         assert all(torch.equal(a, b) for a, b in zip(got2, direct[:2]))
         assert seen.count(threading.current_thread().name) == 2
-        # a second prefetch replaces the first; a single image is a group of one
+        # a second prefetch does not displace the first; a single image is a group of one
         p.prefetch(imgs[2])
+        assert len(p._prefetched) == 2
         assert torch.equal(p._prepared([imgs[2]])[0], direct[2])
+        assert all(torch.equal(a, b) for a, b in zip(p._prepared(imgs), direct)) and p._prefetched == {}
+        assert torch.get_num_threads() == before
     finally:
         p.close_prefetch()
     assert torch.get_num_threads() == before and p._prefetch_pool is None
     p.close_prefetch()                                       # idempotent
     assert p.timings["host_prepare_s"] > 0.0
+
+
+def test_no_crop_is_prepared_twice_when_the_next_group_is_prefetched_before_the_current_one_runs():
+    """the order bench.py and stage/run.py use: prefetch(group g + 1), THEN the call on group g.  Round 4 kept one pending slot,
+    which that order overwrites before the pick-up: every crop but the last group's was prepared twice."""
+    p = _pipeline()
+    groups = [[_crop(10 * g + i) for i in range(2)] for g in range(5)]
+    calls = []
+    orig = p._host_prepare
+    p._host_prepare = lambda im: (calls.append((id(im), threading.current_thread().name)), orig(im))[1]
+    main = threading.current_thread().name
+    try:
+        p.prefetch(groups[0])                                # (the first group of a run is prepared during the group before it)
+        for g in range(5):
+            if g + 1 < 5:
+                p.prefetch(groups[g + 1])
+            got = p._prepared(groups[g])
+            assert len(got) == 2
+    finally:
+        p.close_prefetch()
+    ids = [c[0] for c in calls]
+    assert len(ids) == 10 and len(set(ids)) == 10            # every crop exactly once ...
+    assert all(name != main for _, name in calls)            # ... and never on the calling thread
+    assert p.timings["prefetch_hits"] == 10 and p.timings["host_prepare_n"] == 10
+    # groups nobody comes for do not pile up
+    p2 = _pipeline()
+    try:
+        keep = [[_crop(100 + g)] for g in range(7)]
+        for grp in keep:
+            p2.prefetch(grp)
+        assert len(p2._prefetched) == p2._PREFETCH_MAX_GROUPS
+        assert torch.equal(p2._prepared(keep[-1])[0], p2._host_prepare(keep[-1][0]))
+    finally:
+        p2.close_prefetch()
 
 
 def test_a_crop_that_cannot_be_prepared_raises_at_pick_up():
@@ -78,9 +116,10 @@ def test_a_crop_that_cannot_be_prepared_raises_at_pick_up():
     with pytest.raises(Exception) as direct:
         p._host_prepare(bad)
     try:
-        p.prefetch([_crop(3), bad])
+        grp = [_crop(3), bad]
+        p.prefetch(grp)
         with pytest.raises(type(direct.value)):
-            p._prepared(p._prefetched[1])
+            p._prepared(grp)
     finally:
         p.close_prefetch()
 

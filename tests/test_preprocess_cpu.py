@@ -127,3 +127,28 @@ def test_area_relation_properties_over_random_shapes():
         grow_h, grow_w = H0 + int(rng.integers(1, 20)), W0 + int(rng.integers(1, 20))
         big = P.resize_area_u8(arr, grow_w, grow_h)
         assert big.shape == (grow_h, grow_w, 2) and np.array_equal(big, H.resize_area(arr, grow_w, grow_h))
+
+
+def test_antialiased_bilinear_resize_against_the_real_torch_operator():
+    """conditioner_transform's resize (round 5: numpy / scipy.sparse, so that the host-preparation thread runs no torch operator)
+    against F.interpolate(mode="bilinear", antialias=True) itself -- enlarging (the path's 512 -> 518), shrinking, ragged
+    shapes: one float32 ulp"""
+    import torch
+    import torch.nn.functional as F
+    from hy3dgen.shapegen.preprocessors import conditioner_transform, resize_bilinear_aa, IMAGENET_MEAN, IMAGENET_STD
+    rng = np.random.default_rng(5)
+    for (H, W, nh, nw) in [(64, 64, 70, 70), (512, 512, 518, 518), (512, 512, 224, 224), (300, 200, 518, 345), (100, 130, 37, 51),
+                           (77, 77, 77, 77)]:
+        x = rng.random((3, H, W), dtype=np.float32)
+        a = resize_bilinear_aa(x, nh, nw)
+        b = F.interpolate(torch.from_numpy(x)[None], size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)[0].numpy()
+        assert a.shape == b.shape and a.dtype == np.float32
+        assert np.abs(a - b).max() <= 2.4e-7, (H, W, nh, nw, np.abs(a - b).max())
+    # the whole transform on a non-square image: resize of the short side, centre crop, normalisation
+    img = torch.from_numpy(rng.random((2, 3, 90, 120), dtype=np.float32) * 2 - 1)
+    got = conditioner_transform(img, 70)
+    xr = F.interpolate((img + 1) / 2, size=(70, int(120 * 70 / 90)), mode="bilinear", antialias=True, align_corners=False)
+    left = (xr.shape[-1] - 70) // 2
+    ref = (xr[:, :, :, left:left + 70] - torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    assert got.shape == (2, 3, 70, 70) and got.dtype == torch.float32 and got.is_contiguous()
+    assert torch.allclose(got, ref, atol=2e-6)

@@ -5,7 +5,7 @@ timing rounds (HIP events on the launch stream; median and min per variant), wit
     python tools/bench_gemm.py [--variants 8,9,11] [--rounds 5] [--iters 10] [--screen 6] [--shapes dit,geo,edge]
 
 Variant = value of r3g_set_option("gemm_waves"): 4 / 8 = 128x128 tile, 9 = 256x256 two-stage, 11 = 256x256 phased, 12 = its
-persistent form, 14 = the 4-wave stream kernel (gemm4.hip; falls back to the automatic choice outside its coverage).
+persistent form.
 All variants accumulate every output element over k in the same order on the same MFMA shape, so their results must be
 bit-identical: the screen runs each variant several times per shape (races in the LDS pipeline show up as rare diffs).
 """
@@ -34,7 +34,7 @@ SHAPES = {
     # the DiT's under-filled deep-K residual GEMMs (120 tiles of 256x256): split-K candidates
     "split": [(7552, 1024, 5120, 3), (7552, 1024, 4096, 3), (7552, 1024, 2048, 3), (7552, 1024, 1024, 3)],
     "ksweep": [(131072, 1024, k, e) for e in (0, 3) for k in (128, 256, 512, 1024, 2048)],
-    # the launches of the 4-wave stream kernel (variant 14; gemm4.hip): bf16 outputs, K >= 1024 -- four objects' MLP-in and QKV-shaped
+    # bf16 outputs, K >= 1024 -- four objects' MLP-in and QKV-shaped
     # projections of the DiT, the geo decoder's c_fc, and ragged / single-tile / deeper-K cases for the screen
     "stream": [(30080, 4096, 1024, 1), (30080, 3072, 1024, 0), (131072, 4096, 1024, 2), (131072, 1024, 1024, 0),
                (5000, 512, 1024, 0), (300, 256, 2048, 1), (77, 512, 1152, 2), (1371, 1024, 1024, 1), (7552, 4096, 1024, 1),

@@ -1,3 +1,5 @@
+// NOT PART OF THE LIBRARY (round 5): round 4's 4-wave stream GEMM, kept as the record behind profiles/r04_gemm_stream.md.  It was
+// bit-identical to the phased kernels and measured slower (934 against 985 TF/s); the product library no longer builds it.
 // gemm4.hip -- the bf16-output GEMMs with a short K (K = 1024: MLP-in + GELU, QKV-shaped projections, the geo decoder's c_fc)
 // as ONE stream of k-tiles per compute unit: four waves, one per SIMD, 512 registers each.
 //
