@@ -7,6 +7,7 @@
 // Dinov2: patch embedding unfold, SwiGLU).  One wave64 per row for the row reductions, 16-byte
 // accesses wherever the layout allows.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdint.h>
 
@@ -395,6 +396,14 @@ __global__ void cfg_euler_kernel(float* lat, const float* v2, int64_t n, float g
     lat[i] = lat[i] + ds * (vu + g * (vc - vu));
 }
 
+// *flag |= 1 when x holds a NaN or an infinity (one atomic per wave that saw one)
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n, int* flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= (__float_as_uint(x[i]) & 0x7F800000u) == 0x7F800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 __global__ void swiglu_kernel(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i >= (int64_t)rows * F) return;
@@ -666,6 +675,13 @@ hipError_t fill_rows_launch(float* dst, int64_t ld, int rows, int C, const float
 hipError_t cfg_euler_launch(float* latents, const float* v2, int64_t n, float guidance, float dsigma, hipStream_t s) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, latents, v2, n, guidance, dsigma);
+    return hipGetLastError();
+}
+
+hipError_t nonfinite_flag_launch(const float* x, int64_t n, int* flag, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, x, n, flag);
     return hipGetLastError();
 }
 

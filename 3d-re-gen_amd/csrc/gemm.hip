@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (p.bias) bj = *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : p.N - 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const f32x4 v = gelu_erf4(acc[j][i] + bj) * inv;
+                const f32x4 v = gelu_erf4<false>(acc[j][i] + bj) * inv;
                 int w = 0;
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
@@ -555,6 +555,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         const bool wide = EPI != EPI_F32 && lds_wave != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
                           (p.strideC & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
         if (VM0 && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // PK: the GELU epilogues in packed fp16 (gemm_common.h; run-time option "gelu_pk", one wave-uniform branch per tile)
+        auto body = [&](auto PKC) __attribute__((always_inline)) {
+        constexpr bool PK = decltype(PKC)::value;
 #pragma unroll
         for (int ip = 0; ip < MI; ip += PI) {
 #pragma unroll
@@ -564,8 +567,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     const int i = ip + ii;
                     const int n = ncol + j * 16, m = mrow + i * 16;
                     f32x4 v = acc[j][i] + biasv[j];
-                    if (EPI == EPI_BF16_GELU_TANH) v = gelu_tanh4(v);
-                    else if (EPI == EPI_BF16_GELU_ERF) v = gelu_erf4(v);
+                    if (EPI == EPI_BF16_GELU_TANH) v = gelu_tanh4<PK>(v);
+                    else if (EPI == EPI_BF16_GELU_ERF) v = gelu_erf4<PK>(v);
                     if (EPI != EPI_F32 && wide) {
                         uint2 pk;
                         pk.x = pack_bf16(v[0], v[1]);
@@ -603,6 +606,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+        }
+        };
+        if constexpr (EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) {
+            if (p.gelu_pk) body(std::true_type{});
+            else body(std::false_type{});
+        } else {
+            body(std::false_type{});
         }
     }
 }
@@ -1733,6 +1743,7 @@ int g_gemm_persistent_resid = 0;   // experiment switch (r3g_set_option "gemm_pe
 bool g_gemm_persistent = true;   // phased kernel as a persistent grid when there are more 256x256 tiles than CUs
 bool g_gemm_phased = true;   // 256x256 tiles run the phased (counted-vmcnt) kernel instead of the two-stage one
 bool g_gemm_wide_epilogue = true;
+bool g_gemm_gelu_pk = true;   // GELU epilogues in packed fp16 (gemm_common.h)
 
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStream_t s) {
@@ -1814,6 +1825,7 @@ void gemm_set_auto_rule(int rule, int num_cu) {
     if (num_cu > 0) g_num_cu = num_cu;
 }
 void gemm_set_wide_epilogue(bool on) { g_gemm_wide_epilogue = on; }
+void gemm_set_gelu_pk(bool on) { g_gemm_gelu_pk = on; }
 void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
@@ -1845,11 +1857,13 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     p.batch = batch;
     p.raster_group = g_gemm_raster;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
     p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;
+    p.gelu_pk = g_gemm_gelu_pk ? 1 : 0;
     if (p2_in && p2_in->M > 0 && p2_in->N > 0 && batch2 > 0) {
         p2 = *p2_in;
         p2.batch = batch2;
         p2.raster_group = p.raster_group;
         p2.wide_epilogue = p.wide_epilogue;
+        p2.gelu_pk = p.gelu_pk;
         if (p2.epi != p.epi || !gemm_args_ok(p2)) return hipErrorInvalidValue;
     }
     if (p.M <= 0 || p.N <= 0 || batch <= 0) {

@@ -74,6 +74,7 @@ struct GemmArgs {
     float out_inv_scale;   // EPI_FP8_GELU_ERF: 1 / (the static scale of the fp8 output)
     int wide_epilogue;  // 1: stores go through the wave-private LDS transpose (row-contiguous 16-byte accesses)
     int raster_group;   // tile columns per rasterisation group (0 = row-major), filled in by gemm_launch
+    int gelu_pk;        // 1: GELU epilogues in packed fp16 (gemm_common.h), filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
 };
 
@@ -93,6 +94,7 @@ void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles
 void gemm_set_persistent_resid(int mask);   // persistent form also for the fp32 (bit 0) / bf16 (bit 1) residual epilogues
 void gemm_set_persistent(bool on);   // phased kernel walks several tiles per workgroup (default on)
 void gemm_set_phased(bool on);   // 256x256 tiles: phased kernel (default) or the two-stage one
+void gemm_set_gelu_pk(bool on);   // GELU epilogues in packed fp16 (default on) | fp32 with v_exp_f32 / v_rcp_f32 (rounds 3-4)
 void gemm_set_wide_epilogue(bool on);  // 4|8 waves per 128x128 tile, 2|3 LDS stages
 
 // ------------------------------------------------------------------ attention (attn.hip)
@@ -130,6 +132,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s);
 // factor the producers of Q fold into it for the current attention kernel: scale * log2(e) (generation 2), or 1
 float attn_q_scale(float scale);
 void attn_set_wide_min(int items);     // generation 7: 256-query workgroups (generation 6) from this many work items on (default 2048)
+void attn_set_stages(int r);          // generation 8 (phased 8-wave kernel): LDS ring of 3 | 4 (default) K / V^T stages
 void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
 void ln_set_rows4_min(int rows);     // automatic rule: launches of at least this many rows take 4 rows per wave (65536)
 void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave
@@ -189,6 +192,7 @@ hipError_t cast_pad_launch(const float* in, int64_t ldi, uint16_t* out, int64_t 
 hipError_t fill_rows_launch(float* dst, int64_t ld, int rows, int C, const float* row_values, hipStream_t s);
 // latents += dsigma * (v_u + g (v_c - v_u));  v = [2][n] (cond first)
 hipError_t cfg_euler_launch(float* latents, const float* v2, int64_t n, float guidance, float dsigma, hipStream_t s);
+hipError_t nonfinite_flag_launch(const float* x, int64_t n, int* flag, hipStream_t s);   // *flag |= 1 when x holds a NaN / infinity
 // swiglu: out(bf16)[r][c] = silu(in[r][c]) * in[r][F + c]
 hipError_t swiglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
 // Fourier features of dense grid points [start, start+count): bf16 [count][64] = (xyz, sin(x 2^k).., cos.., 0 pad)

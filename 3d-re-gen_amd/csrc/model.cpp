@@ -60,6 +60,8 @@ static bool g_cfg_dedup = true;   // carry the (uniform) unconditional context a
 static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached intermediate results (Model::GeoCache) are tied to it
 static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
+static bool g_dit_f16_guard = true;    // option "dit_f16_guard": check the latents of an fp16-stream group, fall back to fp32 on overflow
+static int g_dit_f16_fallbacks = 0;    // how often that happened (r3g_set_option("dit_f16_fallbacks_reset", ...) / stderr line)
 static bool g_dit_resid_f16 = true;   // the DiT's residual stream of the de-duplicated CFG path in fp16 (the reference's activation type) instead of fp32
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
 // r3g_flow_sample runs steps [g_flow_first_step, g_flow_last_step) of its schedule (options "flow_first_step" / "flow_last_step";
@@ -108,7 +110,8 @@ struct Model {
     struct DitBatch {
         int cap = 0, nb = 0;
         char* base = nullptr;
-        float *f32a = nullptr, *v2 = nullptr;
+        float *f32a = nullptr, *v2 = nullptr, *lat0 = nullptr;   // lat0: the group's initial latents (fp16-stream overflow guard)
+        int* bad = nullptr;                                        // device flag of that guard
         uint16_t *xn = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *cat = nullptr, *inb = nullptr, *ctx = nullptr;
         int *seg_txt = nullptr, *seg_all = nullptr;
         std::vector<int> h_seg_txt, h_seg_all;
@@ -450,13 +453,14 @@ static int ensure_dit_batch(Model& m, int NB) {
         const size_t o_f = carve(rows * H * 4), o_xn = carve(rows * H * 2), o_q = carve(n_attn * 2), o_k = carve(n_attn * 2),
                      o_v = carve(n_attn * 2), o_cat = carve(rows * 5 * H * 2), o_inb = carve((int64_t)NB * Nl * m.cin_pad * 2),
                      o_ctx = carve((int64_t)NB * Ltp * c.dit_context_dim * 2), o_v2 = carve(2LL * NB * Nl * c.dit_in_channels * 4),
-                     o_seg = carve(2 * 64 * 16);
+                     o_seg = carve(2 * 64 * 16), o_lat0 = carve((int64_t)NB * Nl * c.dit_in_channels * 4), o_bad = carve(256);
         R3G_TRY(hipMalloc((void**)&d.base, off));
         R3G_TRY(hipMemset(d.base, 0, off));   // padded rows / columns must start finite
         char* a = d.base;
         d.f32a = (float*)(a + o_f); d.xn = (uint16_t*)(a + o_xn); d.Q = (uint16_t*)(a + o_q); d.K = (uint16_t*)(a + o_k);
         d.Vt = (uint16_t*)(a + o_v); d.cat = (uint16_t*)(a + o_cat); d.inb = (uint16_t*)(a + o_inb);
         d.ctx = (uint16_t*)(a + o_ctx); d.v2 = (float*)(a + o_v2); d.seg_txt = (int*)(a + o_seg); d.seg_all = d.seg_txt + 64 * 4;
+        d.lat0 = (float*)(a + o_lat0); d.bad = (int*)(a + o_bad);
         d.cap = NB;
         d.nb = 0;
     }
@@ -480,7 +484,8 @@ static int ensure_dit_batch(Model& m, int NB) {
 }
 
 // x_lat f32 [NB][Nl][Cin]; the context rows (m.db.ctx) are filled by the caller; out2 f32 [2*NB][Nl][Cin] (entry order)
-static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, float* out2, int NB, hipStream_t s) {
+static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, float* out2, int NB, hipStream_t s,
+                                 bool allow_f16 = true) {
     const r3g_model_config& c = m.c;
     Model::DitBatch& d = m.db;
     const int H = m.H, Nl = c.vae_num_latents, Lc = m.Lc, T = m.T, Tpad = m.Tpad, heads = m.Hd;
@@ -491,7 +496,7 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
     // The residual stream: fp32, or (option "dit_resid_f16") fp16 -- the reference's own activation type (its pipelines run in
     // fp16) -- in the same buffer: the read-modify-write epilogues of the N = 1024 projections and the LayerNorm reads move
     // half the bytes.  `xrow(r)` = the stream from row r on, in either format.
-    const bool xh = g_dit_resid_f16 && H % 256 == 0;     // (the 16-bit LayerNorm input exists for whole 256-column rows: not CI dims)
+    const bool xh = g_dit_resid_f16 && allow_f16 && H % 256 == 0;     // (the 16-bit LayerNorm input exists for whole 256-column rows: not CI dims)
     const int xfmt = xh ? 2 : 0, epi_res = xh ? EPI_RESID_F16 : EPI_RESID_F32;
     auto xrow = [&](int64_t r) -> void* {
         return xh ? (void*)(reinterpret_cast<uint16_t*>(d.f32a) + r * H) : (void*)(d.f32a + r * H);
@@ -1143,13 +1148,33 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
             R3G_TRY(hipMemcpyAsync(dst + cond_elems, cond2 + cond_elems, (size_t)c.dit_context_dim * 2, hipMemcpyDeviceToDevice, s));
         }
         float* lat = d_latents + o0 * n;
-        for (int i = std::max(0, g_flow_first_step); i < std::min(steps, g_flow_last_step); ++i) {
-            // the final step of upstream's schedule has d_sigma = 0: its update is x += 0 * v, so the evaluation is skipped
-            // (bit-identical; r3g_set_option("skip_zero_step", 0) evaluates it as upstream does)
-            const float ds = sig[i + 1] - sig[i];
-            if (ds == 0.f && g_skip_zero_step) continue;
-            R3G_RC(dit_forward_cfg_dedup(*m, lat, sig[i], d.v2, NB, s));
-            for (int o = 0; o < NB; ++o) R3G_TRY(cfg_euler_launch(lat + o * n, d.v2 + 2 * o * n, n, guidance_scale, ds, s));
+        // The fp16 residual stream (option dit_resid_f16, default) tops out at 65504 where the fp32 stream of rounds 1-3 could not
+        // overflow: the group's initial latents are kept, the final latents are checked for NaN / infinity once per group (one
+        // small kernel and a 4-byte read-back behind ~5 s of GPU work), and a group that overflowed is run again on the fp32
+        // stream -- never silently wrong latents from a checkpoint whose activations outgrow fp16.
+        const bool guard = g_dit_resid_f16 && m->H % 256 == 0 && g_dit_f16_guard;
+        if (guard) R3G_TRY(hipMemcpyAsync(d.lat0, lat, (size_t)NB * n * 4, hipMemcpyDeviceToDevice, s));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool allow_f16 = attempt == 0;
+            for (int i = std::max(0, g_flow_first_step); i < std::min(steps, g_flow_last_step); ++i) {
+                // the final step of upstream's schedule has d_sigma = 0: its update is x += 0 * v, so the evaluation is skipped
+                // (bit-identical; r3g_set_option("skip_zero_step", 0) evaluates it as upstream does)
+                const float ds = sig[i + 1] - sig[i];
+                if (ds == 0.f && g_skip_zero_step) continue;
+                R3G_RC(dit_forward_cfg_dedup(*m, lat, sig[i], d.v2, NB, s, allow_f16));
+                for (int o = 0; o < NB; ++o) R3G_TRY(cfg_euler_launch(lat + o * n, d.v2 + 2 * o * n, n, guidance_scale, ds, s));
+            }
+            if (!guard || attempt == 1) break;
+            int bad = 0;
+            R3G_TRY(hipMemsetAsync(d.bad, 0, 4, s));
+            R3G_TRY(nonfinite_flag_launch(lat, (int64_t)NB * n, d.bad, s));
+            R3G_TRY(hipMemcpyAsync(&bad, d.bad, 4, hipMemcpyDeviceToHost, s));
+            R3G_TRY(hipStreamSynchronize(s));
+            if (!bad) break;
+            ++g_dit_f16_fallbacks;
+            fprintf(stderr, "[r3g] the fp16 residual stream of the DiT overflowed (non-finite latents): this launch group runs again on "
+                            "the fp32 stream (r3g_set_option(\"dit_resid_f16\", 0) makes that the default)\n");
+            R3G_TRY(hipMemcpyAsync(lat, d.lat0, (size_t)NB * n * 4, hipMemcpyDeviceToDevice, s));
         }
     }
     return R3G_OK;
@@ -1277,6 +1302,8 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "geo_q_cache_gb")) g_geo_q_cache_bytes = value < 0 ? -1 : (long long)value << 30;
     else if (!strcmp(name, "geo_resid_bf16")) g_geo_resid_bf16 = value != 0;
     else if (!strcmp(name, "dit_resid_f16")) g_dit_resid_f16 = value != 0;
+    else if (!strcmp(name, "dit_f16_guard")) g_dit_f16_guard = value != 0;
+    else if (!strcmp(name, "gelu_pk")) gemm_set_gelu_pk(value != 0);
     else if (!strcmp(name, "geo_fp8")) g_geo_fp8 = value >= 0 && value <= 3 ? value : 0;
     else if (!strcmp(name, "group_streams")) g_group_streams = value != 0;
     else if (!strcmp(name, "overlap_mlp")) g_overlap_mlp = value != 0;
@@ -1296,6 +1323,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
+    else if (!strcmp(name, "attn_stages")) attn_set_stages(value);
     else if (!strcmp(name, "attn_wide_min")) attn_set_wide_min(value);
     else if (!strcmp(name, "ln_rows")) ln_set_rows_per_wave(value);
     else if (!strcmp(name, "ln_rows4_min")) ln_set_rows4_min(value);

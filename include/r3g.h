@@ -396,7 +396,13 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * budget of geo_q_cache in GiB; < 0, the default: 30 % of the device's memory; a grid that needs more gets a prefix of its passes
  * cached), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
  * activation type -- | 0: in fp32, rounds 1-3; NOT bit-preserving: 50-step latents at full depth 3.3e-3 against 3.0e-3 from the
- * fp32 oracle, tests/test_cfg1_golden_gpu.py; -21 ms per object),
+ * fp32 oracle, tests/test_cfg1_golden_gpu.py; -21 ms per object), "gelu_pk" (1 default: the GELU epilogues of the GEMMs evaluate x S(x) with S in packed fp16 -- csrc/gemm_common.h: a
+ * degree-6 polynomial on v_pk_fma_f16, |error of S| <= 7e-4, +1.2 % on the rel-L2 error behind the bf16 rounding of the output |
+ * 0: rounds 3-4's fp32 forms with v_exp_f32 / v_rcp_f32; NOT bit-preserving), "attn_stages" (4 default | 3: LDS ring of the phased
+ * 8-wave attention kernel, attn_generation 8 -- two halves of four waves one phase apart, matrix phase of one half under the
+ * softmax phase of the other; bit-identical to generations 2 and 6), "dit_f16_guard" (1 default: the final latents of a launch group that ran
+ * on the fp16 stream are checked for NaN / infinity and a group that overflowed runs again on the fp32 stream, with a line on
+ * stderr | 0: no check),
  * "gemm_early_wait" (0 default | 1: the persistent phased kernel waits for the next tile's first k-tile inside the bf16 epilogue, in
  * front of its first store, and enters the k-loop without waiting for the epilogue's store acknowledgements -- measured: no effect), "gemm_persistent_qkv" (0 default | 1: fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel,
  * their epilogue in passes of 32 rows -- measured 17 ms per object slower, profiles/r04_gemm_stream.md), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive

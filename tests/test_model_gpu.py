@@ -731,6 +731,50 @@ def test_cfg_dedup_is_the_same_function(tiny):
     assert rel_l2(c, ref) <= TOL["flow_sample"]
 
 
+def test_fp16_stream_overflow_runs_the_group_again_on_the_fp32_stream():
+    """The DiT's residual stream is fp16 by default (max 65504).  A checkpoint whose activations outgrow that -- here: the input
+    projection scaled by 1e5 on a 256-wide model (the 16-bit stream exists from 256 columns on) -- gives non-finite latents on
+    the fp16 stream; the guard (round 5) notices and runs the launch group again on the fp32 stream: the result IS the
+    fp32 stream's, bit for bit, and finite.  With the guard off the fp16 stream's overflow is what comes back (so this input
+    does force the branch)."""
+    import torch
+    from oracle import hy3d_torch as H
+    from r3g import ffi
+    from r3g import model as M
+    L = ffi.lib()
+    cfg = H.tiny_config()
+    cfg["dit"].update(hidden_size=256, num_heads=4, depth=1, depth_single_blocks=1)
+    sd = bf16_round_matrices(H.synthetic_state_dict(cfg, seed=9))
+    sd["model.latent_in.weight"] = sd["model.latent_in.weight"] * 1e5
+    gpu = M.ShapeModel(cfg, sd, 0, grid_chunk=4096)
+    from parity_support import dit_inputs
+    x, _, cond = dit_inputs(cfg, 3)
+    lat0 = x[0]
+    guarded = gpu.flow_sample(lat0.clone(), cond, 3, 5.0).clone()
+    try:
+        ffi.check(L.r3g_set_option(b"dit_resid_f16", 0))
+        f32 = gpu.flow_sample(lat0.clone(), cond, 3, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"dit_resid_f16", 1))
+    try:
+        ffi.check(L.r3g_set_option(b"dit_f16_guard", 0))
+        raw = gpu.flow_sample(lat0.clone(), cond, 3, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"dit_f16_guard", 1))
+    assert torch.isfinite(f32).all() and torch.equal(guarded, f32)
+    assert not torch.isfinite(raw).all()
+    # an ordinary checkpoint never takes the branch: guard on and off give the same bits
+    sd2 = bf16_round_matrices(H.synthetic_state_dict(cfg, seed=9))
+    gpu2 = M.ShapeModel(cfg, sd2, 0, grid_chunk=4096)
+    a = gpu2.flow_sample(lat0.clone(), cond, 3, 5.0).clone()
+    try:
+        ffi.check(L.r3g_set_option(b"dit_f16_guard", 0))
+        b = gpu2.flow_sample(lat0.clone(), cond, 3, 5.0).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"dit_f16_guard", 1))
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_cfg_dedup_full_width(wide):
     import torch
     x, _, cond = _inputs(wide, 5)
