@@ -15,6 +15,7 @@
 // 4 waves x 32 queries per workgroup share the 64-key K / V^T tiles, double-buffered in LDS through
 // 16-byte LDS-DMA with the bank swizzle on the source chunk index (same scheme as gemm.hip).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -590,8 +591,12 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_fresh(const bf16x8& a, const bf1
 // L2 into LDS -- measured at ~16 B/clk/CU with three 4-wave workgroups per CU, the most a CU sustains -- is a third.
 // ABL: timing-only ablation mask of the non-pipelined body (1 no exp2, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no LDS-DMA in
 // the loop, 32 no per-tile wait + barrier, 64 no V^T reads, 128 no K reads); results are garbage for ABL != 0.
-template <bool GLDS, bool PIPE, int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kernel(AttnArgs p) {
+// WPS: waves per SIMD the register allocation is held to (0: 2 for the pipelined / 8-wave forms, else 3; 4 = round 5's experiment:
+// four workgroups per compute unit at <= 128 registers -- a wave issues one vector instruction per 6 cycles whatever its
+// neighbours do (tools/ubench/valu_rate.hip), so the vector pipe of a SIMD only fills from three waves on and the softmax of a
+// block costs a wave ~440 cycles of issue time against 128 of the matrix pipe)
+template <bool GLDS, bool PIPE, int NW, int ABL = 0, int WPS = 0>
+__global__ __launch_bounds__(NW * 64, WPS ? WPS : ((PIPE || NW == 8) ? 2 : 3)) void attn2_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[(PIPE ? 3 : 2) * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1411,6 +1416,268 @@ __global__ __launch_bounds__(512, 2) void attn5_kernel(AttnArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Generation 9 (round 5, second step): THREE groups of four waves, phases S1 | S2 | M.  Generation 8 measured 0.6-0.7 of generation
+// 2's rate (profiles/r05_attention_phases.md): a phase lasted ~800 cycles, not ~300 -- ONE wave cannot issue its softmax faster than
+// ~4 cycles per plain instruction and ~14 per exponential (~500 cycles for the 63 instructions of a block), whatever the vector
+// pipe could take from several waves, so with two waves per SIMD the softmax phase is the whole period.  Here a workgroup is 12
+// waves (three per SIMD, <= 168 registers) = three groups one phase apart, and a block takes a wave three phases:
+//     S1(n): [first block of a tile, waves 0-7: LDS-DMA of the tile two ahead]  row maximum test, exponentials 0-7
+//     S2(n): LDS reads of the fragments of M(n), exponentials 8-15, bf16 packing, row sum
+//     M(n) : the 8 MFMAs (P V of block n interleaved with the scores of block n + 1), s_setprio(1)
+// so that on every SIMD one wave is in its matrix phase while the two others share the vector pipe (their softmax halves:
+// 2 x ~110 cycles of the pipe per phase against 256 of the matrix pipe).  Arithmetic and order per 32-query block: attn2_kernel's --
+// bit-identical outputs.  LDS ring: 4 stages; global phase of group g: S1(n) = 3n + g, S2(n) = 3n + 1 + g, M(n) = 3n + 2 + g;
+// tile t (blocks 2t, 2t + 1) is read from phase 6t - 2 (group 0, K of block 2t in S2(2t - 1)) to phase 6t + 6 (group 2, V^T of block
+// 2t + 1 in S2(2t + 1)).  Waves 0-7 stage one K and one V^T piece of tile t + 2 each at the top of their S1(2t) (phase >= 6t: the
+// stage's last occupant, tile t - 2, was last read in phase 6t - 6) and wait for THEIR pieces of tile u before the barrier that ends
+// phase 6u - 3 -- group 0 at the end of S1(2u - 1), group 1 at the end of M(2u - 2) -- with vmcnt(2): tile u + 1 stays in flight.
+// PRIO: 0 no priorities | 1 the matrix phase at s_setprio(1) | 2 the two softmax phases at s_setprio(1)
+template <bool STAMP, int PRIO>
+__global__ __launch_bounds__(768, 3) void attn6_kernel(AttnArgs p, unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem6[];
+    char* const smem = smem6;
+    constexpr int R = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;                    // 0, 1, 2: group g runs g phases behind group 0
+    const int ql = lane & 31, hh = lane >> 5;
+    constexpr int QT = 384;
+    int eb, hd, qt;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
+        const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+        attn_work_item<QT>(p, item, eb, hd, qt);
+    }
+    const AttnEntry en = attn_entry(p, eb);
+    const int b = en.buf;
+    const int q = qt * QT + wid * 32 + ql;
+    const int Lq = en.lq, Lk = en.lk;
+    const int kvb = p.kv_batch_stride_zero ? 0 : b;
+    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
+    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
+    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
+
+    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
+    const int nblk = 2 * ntiles;
+    const bool stager = wid < 8;
+    int koff, voff;
+    {
+        const int row = (wid & 7) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);
+        koff = row * 64 + kc * 8;
+        voff = row * p.Lk_pad + kc * 8;
+    }
+    auto stage = [&](int t) {
+        char* dst = smem + (t % R) * STAGE_B;
+        const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
+        const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff),
+                                         (__attribute__((address_space(3))) void*)(dst + (wid & 7) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff),
+                                         (__attribute__((address_space(3))) void*)(dst + TILE_B + (wid & 7) * 1024), 16, 0, 0);
+    };
+    auto wait_tile = [&](int u) {     // this wave's pieces of tile u have landed; tile u + 1 (when it exists) may stay in flight
+        if (u + 1 < ntiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (stager) {
+        stage(0);
+        if (ntiles > 1) stage(1);
+    }
+    bf16x8 qf[4];
+    {
+        const int qrow = q < p.Lq_pad ? q : p.Lq_pad - 1;   // a 384-query tile may reach past the 128-aligned allocation
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qrow * 64 + ks * 16 + hh * 8);
+    }
+    if (!p.q_prescaled) {
+        const float sc = p.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { bf16x8 v; uint32_t u[4]; } w;
+            w.v = qf[ks];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w.u[e] = pack_bf16(__uint_as_float(w.u[e] << 16) * sc, __uint_as_float(w.u[e] & 0xFFFF0000u) * sc);
+            qf[ks] = w.v;
+        }
+    }
+    f32x16 o[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m_run = 0.f, l_run = 0.f;
+    int off[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int row = rb * 32 + ql;
+        off[rb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);
+    }
+    const int bias_key = en.bias_key;
+    const float bias_l2 = p.ragged ? en.bias_log2 : 0.f;
+    const bool pad_tail = ntiles * KV_TILE > Lk;
+
+    // STAMP (timing experiments, option "attn_stamps"): s_memtime ticks of every phase's work (phase start -> barrier arrival) and
+    // of its wait at the barrier, summed per wave and added to stamps[group][S1 work, S1 wait, S2 work, S2 wait, M work, M wait, n]
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0;
+    int st_ph = 0;
+#define R3G_PHASE_END() do { __builtin_amdgcn_sched_barrier(0); \
+        unsigned long long st_t1 = 0; if (STAMP) { st_t1 = __builtin_amdgcn_s_memtime(); } \
+        asm volatile("s_barrier" ::: "memory"); \
+        if (STAMP) { const unsigned long long st_t2 = __builtin_amdgcn_s_memtime(); \
+            st_acc[2 * st_ph] += st_t1 - st_t0; st_acc[2 * st_ph + 1] += st_t2 - st_t1; st_t0 = st_t2; st_ph = st_ph == 2 ? 0 : st_ph + 1; } \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    R3G_PHASE_END();                                  // tiles 0, 1 are in LDS
+    for (int g = 0; g < grp; ++g) R3G_PHASE_END();    // group g starts g phases late
+
+    // scores of block 0, from zero (the stabiliser starts as their exact maximum, in S1(0))
+    f32x16 sA, sB;
+    {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(smem + off[0]);
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (off[0] ^ (ks << 5)));
+            sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sA, 0, 0, 0);
+        }
+    }
+    // One 32-key block: block kb of tile t, scores in `s`; the matrix phase leaves the next block's scores in `s_next` (the two
+    // score blocks alternate between two register sets: a loop-carried single set costs 16 register copies per block).
+    // The empty asm statements PIN a phase's results in that phase: they are volatile, like the barriers, so nothing that feeds
+    // them can sink behind the barrier -- left alone the compiler moved every exponential and conversion of S1 / S2 down to its
+    // first use in M(n) (sched_barrier does not bind IR-level sinking), which made M the whole softmax again.
+    auto block = [&](auto KB, const int t, f32x16& s, f32x16& s_next) __attribute__((always_inline)) {
+        constexpr int kb = decltype(KB)::value;
+        const char* cur = smem + (t % R) * STAGE_B;
+        // ================= S1 =================
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        if (kb == 0 && stager && t + 2 < ntiles) stage(t + 2);
+        if (t == ntiles - 1 && pad_tail) {            // only the last tile holds padded keys / the weighted key
+            const int key_base = t * KV_TILE + kb * 32 + 4 * hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key_base + (r & 3) + 8 * (r >> 2);
+                if (key >= Lk) s[r] = -INFINITY;
+                else if (key == bias_key) s[r] += bias_l2;
+            }
+        }
+        float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+        if (kb == 0 && t == 0) {
+            m_run = half_max(mx);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
+        } else if (__any(q < Lq && !(mx <= SCORE_LIMIT))) {
+            const float grow = fmaxf(half_max(mx), 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-grow);
+            m_run += grow;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] -= grow; s[r] -= grow; }
+        }
+        float pe[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pe[r] = __builtin_amdgcn_exp2f(s[r]);
+        asm volatile("" : "+v"(pe[0]), "+v"(pe[1]), "+v"(pe[2]), "+v"(pe[3]), "+v"(pe[4]), "+v"(pe[5]), "+v"(pe[6]), "+v"(pe[7]));
+        if (kb == 1 && grp == 0) wait_tile(t + 1);
+        R3G_PHASE_END();
+        // ================= S2 =================
+        bf16x8 vf[2][2], kf[4];
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                vf[ks2][db] = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
+        {   // K of the next block (behind the very last block: whatever the ring holds -- those scores are never used)
+            const char* nxt = kb == 0 ? cur : smem + ((t + 1) % R) * STAGE_B;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(nxt + (off[kb ^ 1] ^ (ks << 5)));
+        }
+#pragma unroll
+        for (int r = 8; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(s[r]);
+        uint32_t pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
+        {
+            f32x2 ps = (f32x2){pe[0], pe[1]};
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
+            l_run += ps[0] + ps[1];
+        }
+        asm volatile("" : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]),
+                          "+v"(l_run));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        R3G_PHASE_END();
+        // ================= M =================
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        {
+            union { uint32_t u[4]; bf16x8 v; } pf0, pf1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pf0.u[e] = pk[e]; pf1.u[e] = pk[4 + e]; }
+            // P V of this block (o[db] in the order ks2 = 0, 1: attn2_kernel's) interleaved with the score chain of the next one
+            s_next = mfma_32x32x16_fresh(kf[0], qf[0], negm);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pf0.v, o[0], 0, 0, 0);
+            s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1], s_next, 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], pf0.v, o[1], 0, 0, 0);
+            s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[2], s_next, 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], pf1.v, o[0], 0, 0, 0);
+            s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3], qf[3], s_next, 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][1], pf1.v, o[1], 0, 0, 0);
+        }
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (kb == 0 && grp == 1) wait_tile(t + 1);
+        R3G_PHASE_END();
+    };
+    if (STAMP) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st_acc[k] = 0;
+        st_ph = 0;
+        st_t0 = __builtin_amdgcn_s_memtime();
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        block(std::integral_constant<int, 0>{}, t, sA, sB);
+        block(std::integral_constant<int, 1>{}, t, sB, sA);
+    }
+    if (STAMP && lane == 0 && stamps) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&stamps[grp * 8 + k], st_acc[k]);
+        atomicAdd(&stamps[grp * 8 + 6], (unsigned long long)nblk);
+    }
+
+    const float inv = 1.0f / half_sum(l_run);
+    {
+        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
+        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
+        uint16_t* dst = p.O + orow + hd * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint2 even, odd;
+                even.x = pack_bf16(o[db][8 * gp] * inv, o[db][8 * gp + 1] * inv);
+                even.y = pack_bf16(o[db][8 * gp + 2] * inv, o[db][8 * gp + 3] * inv);
+                odd.x = pack_bf16(o[db][8 * gp + 4] * inv, o[db][8 * gp + 5] * inv);
+                odd.y = pack_bf16(o[db][8 * gp + 6] * inv, o[db][8 * gp + 7] * inv);
+                const u32x2 rx = __builtin_amdgcn_permlane32_swap(even.x, odd.x, false, false);
+                const u32x2 ry = __builtin_amdgcn_permlane32_swap(even.y, odd.y, false, false);
+                uint4 out;
+                out.x = rx[0]; out.y = ry[0]; out.z = rx[1]; out.w = ry[1];
+                if (q < Lq) *reinterpret_cast<uint4*>(dst + db * 32 + 16 * gp + 8 * hh) = out;
+            }
+    }
+    for (int g = grp; g < 2; ++g) R3G_PHASE_END();    // the later groups' last phases end with barriers of their own
+#undef R3G_PHASE_END
+}
+
 }  // namespace
 
 static bool g_attn_glds = true;
@@ -1426,7 +1693,11 @@ static int g_attn_gen = 7;
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
 static int g_wide6_min_items = 2048;
 void attn_set_wide_min(int items) { if (items > 0) g_wide6_min_items = items; }
-void attn_set_generation(int gen) { if (gen >= 1 && gen <= 9) g_attn_gen = gen; }
+void attn_set_generation(int gen) { if (gen >= 1 && gen <= 10) g_attn_gen = gen; }
+static int g_attn6_prio = 1;       // option "attn_prio": generation 9's s_setprio use (0 none | 1 matrix phase | 2 softmax phases)
+void attn_set_prio(int v) { if (v >= 0 && v <= 2) g_attn6_prio = v; }
+static int g_attn_stamps = 0;      // option "attn_stamps": generation 9 prints its per-phase s_memtime sums (timing experiments)
+void attn_set_stamps(int on) { g_attn_stamps = on; }
 static int g_attn5_stages = 4;     // LDS ring of the phased kernel (generation 8): 3 or 4 stages of 16 KiB
 void attn_set_stages(int r) { if (r == 3 || r == 4) g_attn5_stages = r; }
 // (the first-generation kernels -- attn_generation 1 and the attn_pipelined option -- scale the scores themselves and
@@ -1463,8 +1734,41 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         };
         int gen = g_attn_gen;
         if (gen == 7) gen = (g_attn_glds && count(256) >= g_wide6_min_items) ? 6 : 2;
-        const int qtile = (g_attn_glds && gen >= 4) ? 256 : 128;
+        const int qtile = (g_attn_glds && gen == 9) ? 384 : (g_attn_glds && gen >= 4 && gen != 10) ? 256 : 128;
         const int items = count(qtile);
+        if (gen == 9 && g_attn_glds) {     // phased 12-wave kernel (round 5): three groups, S1 | S2 | M
+            const int prio = g_attn6_prio;
+            auto launch6 = [&](auto ST, unsigned long long* d_st) -> hipError_t {
+                constexpr bool kSt = decltype(ST)::value;
+                auto k0 = attn6_kernel<kSt, 0>;
+                auto k1 = attn6_kernel<kSt, 1>;
+                auto k2 = attn6_kernel<kSt, 2>;
+                auto k = prio == 0 ? k0 : (prio == 2 ? k2 : k1);
+                if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_B) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return hipErrorNotSupported;
+                }
+                hipLaunchKernelGGL(k, dim3(items), dim3(768), 4 * STAGE_B, s, p, d_st);
+                return hipGetLastError();
+            };
+            if (g_attn_stamps) {       // timing experiment: per-phase s_memtime sums of this launch, printed to stderr (synchronous)
+                static unsigned long long* d_st = nullptr;
+                if (!d_st && hipMalloc((void**)&d_st, 24 * 8) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipMemsetAsync(d_st, 0, 24 * 8, s);
+                const hipError_t e = launch6(std::true_type{}, d_st);
+                if (e != hipSuccess) return e;
+                unsigned long long h[24];
+                if (hipMemcpyAsync(h, d_st, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                    return hipGetLastError();
+                for (int g = 0; g < 3; ++g) {
+                    const double n = (double)(h[g * 8 + 6] ? h[g * 8 + 6] : 1);
+                    fprintf(stderr, "[attn6 stamps] prio %d group %d: ticks per block and wave: S1 %.0f + wait %.0f | S2 %.0f + wait %.0f | M %.0f + wait %.0f\n", prio, g,
+                            h[g * 8] / n, h[g * 8 + 1] / n, h[g * 8 + 2] / n, h[g * 8 + 3] / n, h[g * 8 + 4] / n, h[g * 8 + 5] / n);
+                }
+                return hipSuccess;
+            }
+            return launch6(std::false_type{}, nullptr);
+        }
         if (gen == 8 && g_attn_glds) {     // phased 8-wave kernel (round 5): one workgroup per compute unit
             static int state = 0;          // 0 unknown, 1 usable, -1 the device refuses the dynamic LDS size
             if (state == 0) {
@@ -1492,6 +1796,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         else if (gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 6) hipLaunchKernelGGL((attn3_kernel<4>), dim3(items), dim3(256), 0, s, p);
+        else if (gen == 10) hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 4>), dim3(items), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
         return hipGetLastError();
     }

@@ -93,19 +93,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-// ---- pass 2: one thread per (sample, group) combines the blocks' partials in block order 0, 1, 2, ... (fp64: the same sum
-// whatever the launch geometry) -> (mean, rstd).  Rounds 2-3 had EVERY block of pass 3 redo this sum: 256 blocks x 32 threads
-// x 256 dependent double loads in front of the normalisation.
+// ---- pass 2: one WAVE per (sample, group) combines the blocks' partials -> (mean, rstd): lane l adds the partials of blocks
+// l, l + 64, l + 128, ... in that order, then a fixed shuffle tree (xor 32, 16, ..., 1) adds the lanes -- fp64 and a fixed order, so
+// the result is a pure function of the partials whatever the launch geometry.  Round 4 had one THREAD per (sample, group) walk
+// all blocks: 256 dependent double additions behind strided loads, 26 us per call for a few hundred additions (6.8 % of the
+// texture step's kernel time, profiles/r04_texture_stage.md); rounds 2-3 had every block of pass 3 redo the sum.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const double* __restrict__ partial, int nblk, int groups, int rows, int cpg,
                                                        float eps, float* __restrict__ stats) {
-    const int g = threadIdx.x, smp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), smp = blockIdx.y;
     if (g >= groups) return;
-    const double* p = partial + (int64_t)smp * nblk * groups * 2;
+    const double2* p = reinterpret_cast<const double2*>(partial) + (int64_t)smp * nblk * groups + g;
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += p[((int64_t)b * groups + g) * 2];
-        ss += p[((int64_t)b * groups + g) * 2 + 1];
+    for (int b = lane; b < nblk; b += 64) {
+        const double2 v = p[(int64_t)b * groups];
+        s += v.x;
+        ss += v.y;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d, 64);
+        ss += __shfl_xor(ss, d, 64);
+    }
+    if (lane) return;
     const double n = (double)rows * cpg;
     const double mean = s / n;
     double var = ss / n - mean * mean;      // biased, as torch.nn.GroupNorm
@@ -307,7 +317,7 @@ hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const 
     float* stats = reinterpret_cast<float*>(partial + (int64_t)nb * nblk * groups * 2);
     ProfScope prof_scope_(PC_LAYERNORM, 0.0, s);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, rpb, partial);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nb), dim3(256), 0, s, (const double*)partial, nblk, groups, rows, C / groups, eps, stats);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((groups + 3) / 4, nb), dim3(256), 0, s, (const double*)partial, nblk, groups, rows, C / groups, eps, stats);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, (const float*)stats, gamma, beta,
                        do_silu, rpb, y);
     return hipGetLastError();

@@ -46,7 +46,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // modifier), seven fused multiply-adds and the clamped last one (11 instructions) for a PAIR of values, then one v_fma_mix_f32 per value for
 // x * S in fp32 -- 6.5 issue slots per value against 6 plain + 2 quarter-rate transcendentals (= 14 slots of the vector pipe) for
 // x * rcp(1 + exp2(.)).  The clamp modifiers make the ends exact: for |x| >= 4 the constraint gives S = 0.5 +- 0.5 exactly, so
-// gelu(x) = x resp. -0 there (the true values differ from that by < 7e-5), +infinity included (-inf * 0 is NaN, as x Phi(x) is in
+// gelu(x) = x resp. 0 there (the true values differ from that by < 7e-5), +infinity included (-inf * 0 is NaN, as x Phi(x) is in
 // the reference's own arithmetic); NaN stays NaN.
 // What it costs in accuracy: S carries ~1.6e-4 rms of fp16 rounding; behind the bf16 rounding of the output (1.66e-3 rms relative)
 // the relative L2 error of the stored values grows from 1.655e-3 to 1.675e-3 (+1.2 %), with no bias (2.6e-6 relative).

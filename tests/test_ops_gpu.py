@@ -190,9 +190,9 @@ def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, sh
     Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, shared, Lq + 3 * Lk)
     outs = []
     try:
-        # generation 8 (round 5): the phased 8-wave kernel, with its 4-stage and its 3-stage LDS ring -- the same arithmetic in
+        # generations 8 / 9 (round 5): the phased 8-wave kernel (4- and 3-stage LDS ring) and the 12-wave one -- the same arithmetic in
         # the same order per 32-query block, so the same bits
-        for gen, stages in ((2, 4), (6, 4), (8, 4), (8, 3)):
+        for gen, stages in ((2, 4), (6, 4), (8, 4), (8, 3), (9, 4)):
             ffi.check(L.r3g_set_option(b"attn_generation", gen))
             ffi.check(L.r3g_set_option(b"attn_stages", stages))
             o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
@@ -208,7 +208,7 @@ def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, sh
         assert torch.equal(outs[0], o)
 
 
-@pytest.mark.parametrize("gen", [2, 6, 8])
+@pytest.mark.parametrize("gen", [2, 6, 8, 9])
 def test_attention_ignores_stale_rows_past_lq(env, gen):
     """The query rows between Lq and the padded length hold whatever an earlier launch left there.  They are computed and
     dropped; they must not steer the wave-uniform re-stabilise branch either, or the rounding of the valid queries of
@@ -232,7 +232,7 @@ def test_attention_ignores_stale_rows_past_lq(env, gen):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("gen", [2, 6, 8])
+@pytest.mark.parametrize("gen", [2, 6, 8, 9])
 def test_attention_forced_rescale(env, gen):
     """One key row spiked against one query so the running max jumps late in the sequence
     (exercises the online-softmax rescale branch with a large factor)."""
@@ -300,8 +300,9 @@ def test_gelu_packed_fp16_form_equals_its_emulation(env, epi):
     M, N = 16384, 64
     g = torch.Generator(device="cuda").manual_seed(10 + epi)
     x = (torch.randn(M, N, device="cuda", generator=g) * 2.0).to(torch.bfloat16)
-    x[0, :8] = torch.tensor([4.0, -4.0, 1e4, -1e4, float("inf"), float("-inf"), 0.0, -0.0], device="cuda").to(torch.bfloat16)
-    x[1, 0] = float("nan")
+    # (no infinities / NaN here: through the identity GEMM an infinite value turns its whole row into inf * 0 = NaN; the
+    # emulation's handling of them is checked on the CPU, tests/test_gelu_pk_cpu.py)
+    x[0, :6] = torch.tensor([4.0, -4.0, 1e4, -1e4, 0.0, -0.0], device="cuda").to(torch.bfloat16)
     w = torch.eye(N, device="cuda").to(torch.bfloat16)
     c = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     ffi.check(L.r3g_op_gemm(x.data_ptr(), N, w.data_ptr(), N, None, c.data_ptr(), N, None, M, N, N, epi, 1, stream(torch)))
@@ -311,9 +312,8 @@ def test_gelu_packed_fp16_form_equals_its_emulation(env, epi):
     nan = np.isnan(xf) | np.isnan(want)        # (x = -inf: -inf * 0 = NaN, as in the reference's own x * Phi(x))
     assert np.isnan(got[nan]).all() and np.isnan(want[nan]).all()
     assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
-    assert got[0, 0] == 4.0 and got[0, 1] == 0.0 and got[0, 2] == 1e4 and got[0, 3] == 0.0 and got[0, 4] == np.inf
+    assert got[0, 0] == 4.0 and got[0, 1] == 0.0 and got[0, 2] == xf[0, 2] and got[0, 3] == 0.0 and got[0, 4] == 0.0
     ok = np.isfinite(xf)
-    assert np.isnan(got[0, 5])
     S = G.S_erf if epi == 2 else G.S_tanh
     ref = xf[ok].astype(np.float64) * S(xf[ok].astype(np.float64))
     exact = G.bf16_rne(ref.astype(np.float32)).astype(np.float64)

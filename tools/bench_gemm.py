@@ -39,6 +39,8 @@ SHAPES = {
     "stream": [(30080, 4096, 1024, 1), (30080, 3072, 1024, 0), (131072, 4096, 1024, 2), (131072, 1024, 1024, 0),
                (5000, 512, 1024, 0), (300, 256, 2048, 1), (77, 512, 1152, 2), (1371, 1024, 1024, 1), (7552, 4096, 1024, 1),
                (256, 256, 1024, 0), (4442, 768, 1536, 0)],
+    # round 5: the two GELU launches of the path (four objects' MLP-in, the geo decoder's c_fc) and a plain one beside them
+    "gelu": [(30080, 4096, 1024, 1), (131072, 4096, 1024, 2), (30080, 3072, 1024, 0)],
     # ragged edges for the screen
     "edge": [(300, 256, 128, 0), (77, 512, 256, 3), (1371, 1024, 1024, 1), (515, 768, 1024, 3), (4442, 1024, 1536, 4),
              (256, 256, 128, 2), (256, 384, 256, 0), (1000, 448, 384, 1)],
@@ -65,14 +67,18 @@ def main():
     ap.add_argument("--screen", type=int, default=6)
     ap.add_argument("--shapes", default="edge,dit,geo")
     ap.add_argument("--no-lt", action="store_true")
+    ap.add_argument("--gelu-pk", default="1", help="comma list of r3g_set_option(\"gelu_pk\") values to time side by side (1: packed "
+                                                  "fp16 GELU epilogue, round 5 | 0: the fp32 forms); variants are then keyed 'v/pk'")
     a_ = ap.parse_args()
-    variants = [int(v) for v in a_.variants.split(",")]
+    pks = [int(v) for v in a_.gelu_pk.split(",")]
+    variants = [int(v) * 10 + pk for v in a_.variants.split(",") for pk in pks]     # variant * 10 + gelu_pk
     ffi.context(0)
     L = ffi.lib()
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run(v, a, w, bias, gate, c, M, N, K, epi):
-        ffi.check(L.r3g_set_option(b"gemm_waves", v))
+        ffi.check(L.r3g_set_option(b"gemm_waves", v // 10))
+        ffi.check(L.r3g_set_option(b"gelu_pk", v % 10))
         ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
                                 gate.data_ptr() if epi in (3, 6) else None, M, N, K, epi, 1, s))
 
@@ -83,8 +89,11 @@ def main():
 
             def fresh():
                 return c0.clone() if epi in (3, 6) else torch.full((M, N), float("nan"), device="cuda", dtype=dt)
-            ref = fresh()
-            run(8, a, w, bias, gate, ref, M, N, K, epi)
+            refs = {}
+            for pk in pks:
+                refs[pk] = fresh()
+                run(80 + pk, a, w, bias, gate, refs[pk], M, N, K, epi)
+            ref = refs[pks[0]]
             lin = a.float() @ w.float().t() + bias
             if epi == 1:
                 want = torch.nn.functional.gelu(lin, approximate="tanh")
@@ -101,8 +110,8 @@ def main():
                 for it in range(a_.screen):
                     c = fresh()
                     run(v, a, w, bias, gate, c, M, N, K, epi)
-                    if not torch.equal(c, ref):
-                        d = (c.float() - ref.float()).abs()
+                    if not torch.equal(c, refs[v % 10]):
+                        d = (c.float() - refs[v % 10].float()).abs()
                         bad.setdefault(v, []).append((it, int((d > 0).sum()), float(d.max())))
             rec = dict(op="screen", M=M, N=N, K=K, epi=epi, rel_l2_vs_fp32=rel, mismatches={str(k): v for k, v in bad.items()})
             print(json.dumps(rec), flush=True)
@@ -131,11 +140,12 @@ def main():
             fl = 2.0 * M * N * K
             for v, ts in times.items():
                 med, mn = statistics.median(ts), min(ts)
-                print(json.dumps(dict(op="gemm", M=M, N=N, K=K, epi=epi, variant=v, us_med=1e3 * med, us_min=1e3 * mn,
+                print(json.dumps(dict(op="gemm", M=M, N=N, K=K, epi=epi, variant=v if v == "lt" else "%d/pk%d" % (v // 10, v % 10), us_med=1e3 * med, us_min=1e3 * mn,
                                       tflops_med=fl / med / 1e9, tflops_best=fl / mn / 1e9)), flush=True)
-            del a, w, c, ref
+            del a, w, c, ref, refs
             torch.cuda.empty_cache()
     ffi.check(L.r3g_set_option(b"gemm_waves", 0))
+    ffi.check(L.r3g_set_option(b"gelu_pk", 1))
 
 
 if __name__ == "__main__":

@@ -56,10 +56,11 @@ def emulate_s(x, erf):
 
 
 def emulate(x, erf):
-    """the bf16 value the GELU epilogue stores for the fp32 value x (v_fma_mix_f32: x * S in fp32, then round to bf16)"""
+    """the bf16 value the GELU epilogue stores for the fp32 value x (v_fma_mix_f32: fma(x, S, +0) in fp32 -- a product of -0
+    comes out as +0 --, then round to bf16)"""
     x = np.asarray(x, np.float32)
     with np.errstate(invalid="ignore"):
-        g = (x.astype(np.float64) * emulate_s(x, erf).astype(np.float64)).astype(np.float32)    # one fp32 rounding of the exact product
+        g = (x.astype(np.float64) * emulate_s(x, erf).astype(np.float64) + 0.0).astype(np.float32)    # one fp32 rounding of the exact product
     return bf16_rne(g)
 
 
