@@ -591,12 +591,10 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_fresh(const bf16x8& a, const bf1
 // L2 into LDS -- measured at ~16 B/clk/CU with three 4-wave workgroups per CU, the most a CU sustains -- is a third.
 // ABL: timing-only ablation mask of the non-pipelined body (1 no exp2, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no LDS-DMA in
 // the loop, 32 no per-tile wait + barrier, 64 no V^T reads, 128 no K reads); results are garbage for ABL != 0.
-// WPS: waves per SIMD the register allocation is held to (0: 2 for the pipelined / 8-wave forms, else 3; 4 = round 5's experiment:
-// four workgroups per compute unit at <= 128 registers -- a wave issues one vector instruction per 6 cycles whatever its
-// neighbours do (tools/ubench/valu_rate.hip), so the vector pipe of a SIMD only fills from three waves on and the softmax of a
-// block costs a wave ~440 cycles of issue time against 128 of the matrix pipe)
-template <bool GLDS, bool PIPE, int NW, int ABL = 0, int WPS = 0>
-__global__ __launch_bounds__(NW * 64, WPS ? WPS : ((PIPE || NW == 8) ? 2 : 3)) void attn2_kernel(AttnArgs p) {
+// (Round 5 also tried this body at FOUR waves per SIMD -- four workgroups per compute unit, registers capped at 128: 22 spilled
+// registers inside the key loop, 905 against 995 TFLOP/s on the geo decoder's passes; profiles/r05_attention_phases.md.)
+template <bool GLDS, bool PIPE, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[(PIPE ? 3 : 2) * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1176,259 +1174,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
 
 
 // ------------------------------------------------------------------------------------------------------------
-// Fifth generation (round 5): EXPLICIT inter-wave phases.  The counters of round 4 (profiles/r04_attention_bound.md) say that
-// at head dim 64 a 32 x 32 score block costs the matrix pipe 256 cycles and the vector pipe ~225, that the two pipes run together
-// for only 39-53 % of the matrix cycles and that NEITHER runs for ~30 % of the time: waves of independent workgroups meet on a
-// SIMD in whatever phase they happen to be in.  Here a workgroup is 8 waves = two HALVES of four (wave w and wave w + 4 share a
-// SIMD), every wave owns 32 queries, and a wave's loop over the 32-key blocks is cut into two phases separated by workgroup
-// barriers:
-//     S(n): softmax of block n (row maximum test, 16 exponentials, bf16 packing, row sum) -- vector pipe only; at its start the
-//           wave also issues the LDS reads of the fragments its next matrix phase needs (V^T of block n, K of block n + 1) and,
-//           on the first block of a key tile, its share of the LDS-DMA of the tile R - 1 ahead;
-//     M(n): O^T += V^T(n) P^T(n), then the scores of block n + 1 -- 8 MFMAs on operands that are already in registers, wrapped
-//           in s_setprio(1).
-// The second half runs ONE PHASE BEHIND the first (one extra barrier in front of its loop, one behind the first half's), so on
-// every SIMD one wave is in its matrix phase while the other is in its softmax: the pipes overlap by construction instead of
-// by chance.  Per wave and block the arithmetic, its order and the re-stabilise decisions are those of attn2_kernel (the loop is
-// that kernel's body rotated by one third: [S(n); PV(n); QK(n + 1)]), so the outputs are BIT-IDENTICAL to generations 2 and 6.
-// K / V^T tiles: a ring of R stages of 16 KiB in LDS (one workgroup per compute unit: 160 KiB are there), every wave stages one
-// 1 KiB piece of each tile by LDS-DMA, R - 1 tiles ahead; waits are COUNTED (vmcnt(2R - 4): the later tiles stay in flight across
-// the barriers).  Hazards (global phase index: first half S(n) = 2n, M(n) = 2n + 1; second half one later; tile t = blocks 2t, 2t + 1):
-//   * tile t is first read in phase 4t - 2 (first half, K of block 2t, prefetched in its S(2t - 1)): every wave waits for ITS
-//     pieces of tile t before the barrier that ends phase 4t - 3 -- first half at the end of M(2t - 2), second half at the end of
-//     S(2t - 2);
-//   * tile t is last read in phase 4t + 3 (second half, V^T of block 2t + 1); its stage is refilled by the DMA of tile t + R,
-//     issued at the top of S(2t + 2) = phase 4t + 4 at the earliest, behind the barrier that ends phase 4t + 3 and behind the
-//     reader's own lgkmcnt(0) in front of that barrier.
-template <int R>
-__global__ __launch_bounds__(512, 2) void attn5_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem5[];
-    char* const smem = smem5;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wid >> 2;                   // 0: leading half, 1: one phase behind
-    const int ql = lane & 31, hh = lane >> 5;
-    constexpr int QT = 256;
-    int eb, hd, qt;
-    {
-        const int nwg = gridDim.x, orig = blockIdx.x;
-        const int qn = nwg >> 3, rn = nwg & 7, xcd = orig & 7;
-        const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
-        attn_work_item<QT>(p, item, eb, hd, qt);
-    }
-    const AttnEntry en = attn_entry(p, eb);
-    const int b = en.buf;
-    const int q = qt * QT + wid * 32 + ql;
-    const int Lq = en.lq, Lk = en.lk;
-    const int kvb = p.kv_batch_stride_zero ? 0 : b;
-    const uint16_t* Qg = p.Q + (((int64_t)b * p.H + hd) * p.Lq_pad) * 64;
-    const uint16_t* Kg = p.K + (((int64_t)kvb * p.H + hd) * p.Lk_pad) * 64;
-    const uint16_t* Vtg = p.Vt + (((int64_t)kvb * p.H + hd) * 64) * (int64_t)p.Lk_pad;
-
-    const int ntiles = (Lk + KV_TILE - 1) / KV_TILE;
-    const int nblk = 2 * ntiles;
-    // staging: this lane's 16-byte chunk of the wave's 1 KiB piece of a K tile and of a V^T tile
-    int koff, voff;
-    {
-        const int row = wid * 8 + (lane >> 3);
-        const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        koff = row * 64 + kc * 8;
-        voff = row * p.Lk_pad + kc * 8;
-    }
-    auto stage = [&](int t) {
-        char* dst = smem + (t % R) * STAGE_B;
-        const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
-        const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff),
-                                         (__attribute__((address_space(3))) void*)(dst + wid * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff),
-                                         (__attribute__((address_space(3))) void*)(dst + TILE_B + wid * 1024), 16, 0, 0);
-    };
-    // this wave's pieces of tile t have landed: the tiles behind it (at most R - 2 of them, two pieces each) may stay in flight
-    auto wait_tile = [&](int t) {
-        if (t + R - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * R - 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-#pragma unroll
-    for (int t = 0; t < R - 1; ++t)
-        if (t < ntiles) stage(t);
-
-    bf16x8 qf[4];
-    {
-        const int qrow = q < p.Lq_pad ? q : p.Lq_pad - 1;   // a 256-query tile may reach past the 128-aligned allocation
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qrow * 64 + ks * 16 + hh * 8);
-    }
-    if (!p.q_prescaled) {
-        const float sc = p.scale * 1.4426950408889634f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            union { bf16x8 v; uint32_t u[4]; } w;
-            w.v = qf[ks];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                w.u[e] = pack_bf16(__uint_as_float(w.u[e] << 16) * sc, __uint_as_float(w.u[e] & 0xFFFF0000u) * sc);
-            qf[ks] = w.v;
-        }
-    }
-    f32x16 o[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-    float m_run = 0.f, l_run = 0.f;
-    int off[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int row = rb * 32 + ql;
-        off[rb] = row * 128 + ((hh ^ ((row >> 1) & 7)) << 4);
-    }
-    const int bias_key = en.bias_key;
-    const float bias_l2 = p.ragged ? en.bias_log2 : 0.f;
-    const bool pad_tail = ntiles * KV_TILE > Lk;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");          // tiles 0 .. R - 2 are in LDS
-    __builtin_amdgcn_sched_barrier(0);
-    if (half) {                                       // the second half starts one phase late
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // scores of block 0, from zero (the stabiliser starts as their exact maximum, in S(0))
-    f32x16 s;
-    {
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(smem + off[0]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
-#pragma unroll
-        for (int ks = 1; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (off[0] ^ (ks << 5)));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-    }
-    for (int n = 0; n < nblk; ++n) {
-        const int t = n >> 1, kb = n & 1;
-        const char* cur = smem + (t % R) * STAGE_B;
-        // ================= S(n) =================
-        if (kb == 0 && t + R - 1 < ntiles) stage(t + R - 1);
-        bf16x8 vf[2][2], kf[4];
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-                vf[ks2][db] = *reinterpret_cast<const bf16x8*>(cur + TILE_B + (off[db] ^ ((2 * kb + ks2) << 5)));
-        const bool more = n + 1 < nblk;
-        if (more) {
-            const char* nxt = smem + (((n + 1) >> 1) % R) * STAGE_B;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(nxt + (off[(n + 1) & 1] ^ (ks << 5)));
-        }
-        if (t == ntiles - 1 && pad_tail) {            // only the last tile holds padded keys / the weighted key
-            const int key_base = t * KV_TILE + kb * 32 + 4 * hh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key_base + (r & 3) + 8 * (r >> 2);
-                if (key >= Lk) s[r] = -INFINITY;
-                else if (key == bias_key) s[r] += bias_l2;
-            }
-        }
-        float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
-        if (n == 0) {
-            m_run = half_max(mx);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
-        } else if (__any(q < Lq && !(mx <= SCORE_LIMIT))) {
-            const float grow = fmaxf(half_max(mx), 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-grow);
-            m_run += grow;
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] -= grow; s[r] -= grow; }
-        }
-        float pe[16];
-        uint32_t pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(s[r]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
-        {
-            f32x2 ps = (f32x2){pe[0], pe[1]};
-#pragma unroll
-            for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
-            l_run += ps[0] + ps[1];
-        }
-        if (half == 1 && kb == 0) wait_tile(t + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ================= M(n) =================
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            union { uint32_t u[4]; bf16x8 v; } pf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pf.u[e] = pk[4 * ks2 + e];
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks2][db], pf.v, o[db], 0, 0, 0);
-        }
-        if (more) {
-            s = mfma_32x32x16_fresh(kf[0], qf[0], negm);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (half == 0 && kb == 0) wait_tile(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    const float inv = 1.0f / half_sum(l_run);
-    {
-        int64_t orow = (int64_t)b * p.strideO + (int64_t)q * p.ldo;
-        if (p.ragged) orow = attn_entry_out_row(eb, q) * p.ldo;
-        uint16_t* dst = p.O + orow + hd * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                uint2 even, odd;
-                even.x = pack_bf16(o[db][8 * gp] * inv, o[db][8 * gp + 1] * inv);
-                even.y = pack_bf16(o[db][8 * gp + 2] * inv, o[db][8 * gp + 3] * inv);
-                odd.x = pack_bf16(o[db][8 * gp + 4] * inv, o[db][8 * gp + 5] * inv);
-                odd.y = pack_bf16(o[db][8 * gp + 6] * inv, o[db][8 * gp + 7] * inv);
-                const u32x2 rx = __builtin_amdgcn_permlane32_swap(even.x, odd.x, false, false);
-                const u32x2 ry = __builtin_amdgcn_permlane32_swap(even.y, odd.y, false, false);
-                uint4 out;
-                out.x = rx[0]; out.y = ry[0]; out.z = rx[1]; out.w = ry[1];
-                if (q < Lq) *reinterpret_cast<uint4*>(dst + db * 32 + 16 * gp + 8 * hh) = out;
-            }
-    }
-    if (!half) {                                      // the second half's last matrix phase ends with a barrier of its own
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// Generation 9 (round 5, second step): THREE groups of four waves, phases S1 | S2 | M.  Generation 8 measured 0.6-0.7 of generation
-// 2's rate (profiles/r05_attention_phases.md): a phase lasted ~800 cycles, not ~300 -- ONE wave cannot issue its softmax faster than
-// ~4 cycles per plain instruction and ~14 per exponential (~500 cycles for the 63 instructions of a block), whatever the vector
-// pipe could take from several waves, so with two waves per SIMD the softmax phase is the whole period.  Here a workgroup is 12
-// waves (three per SIMD, <= 168 registers) = three groups one phase apart, and a block takes a wave three phases:
+// Generation 9 (round 5; opt-in, `attn_generation` 9): EXPLICIT inter-wave phases, the structure VERDICT r4 item 2 asked for.
+// Round 4's counters (profiles/r04_attention_bound.md) say the two pipes run together for only 39-53 % of the matrix cycles and
+// NEITHER runs ~30 % of the time: waves of independent workgroups meet on a SIMD in whatever phase they happen to be in.  The first
+// attempt (two halves of four waves, softmax | matrix phase, one phase apart: "generation 8", removed again) measured 0.6-0.7 of
+// generation 2's rate, and tools/ubench/valu_rate.hip says why: ONE wave issues a plain vector instruction every 6 cycles and an
+// exponential every 10, whatever the vector pipe could take from its neighbours -- ~440 cycles for the 63 instructions of a block
+// against 8 x 16 cycles of the matrix pipe --, so with two waves per SIMD the softmax phase is the whole period.  Here a workgroup is
+// 12 waves (three per SIMD, <= 168 registers) = three groups one phase apart, and a block takes a wave three phases:
 //     S1(n): [first block of a tile, waves 0-7: LDS-DMA of the tile two ahead]  row maximum test, exponentials 0-7
 //     S2(n): LDS reads of the fragments of M(n), exponentials 8-15, bf16 packing, row sum
 //     M(n) : the 8 MFMAs (P V of block n interleaved with the scores of block n + 1), s_setprio(1)
-// so that on every SIMD one wave is in its matrix phase while the two others share the vector pipe (their softmax halves:
-// 2 x ~110 cycles of the pipe per phase against 256 of the matrix pipe).  Arithmetic and order per 32-query block: attn2_kernel's --
-// bit-identical outputs.  LDS ring: 4 stages; global phase of group g: S1(n) = 3n + g, S2(n) = 3n + 1 + g, M(n) = 3n + 2 + g;
+// so that on every SIMD one wave is in its matrix phase while the two others share the vector pipe.  Arithmetic and order per
+// 32-query block: attn2_kernel's -- bit-identical outputs (tests/test_ops_gpu.py).  MEASURED (profiles/r05_attention_phases.md):
+// 852-868 TFLOP/s on the geo decoder's passes against 995-1027 for generations 2 / 6, 640 against 820-834 on the DiT's shape: the
+// s_memtime stamps (option attn_stamps) show the two softmax phases at ~1.6x the matrix phase in every setting of s_setprio -- the
+// per-wave issue rate again: S1 + S2 is one wave's ~440+ cycles, M is 128, and with <= 3 waves per SIMD no rotation balances that.
+// Default stays generation 7 (= 2 / 6); this kernel is kept as the measured answer to the review's question.  LDS ring: 4 stages; global phase of group g: S1(n) = 3n + g, S2(n) = 3n + 1 + g, M(n) = 3n + 2 + g;
 // tile t (blocks 2t, 2t + 1) is read from phase 6t - 2 (group 0, K of block 2t in S2(2t - 1)) to phase 6t + 6 (group 2, V^T of block
 // 2t + 1 in S2(2t + 1)).  Waves 0-7 stage one K and one V^T piece of tile t + 2 each at the top of their S1(2t) (phase >= 6t: the
 // stage's last occupant, tile t - 2, was last read in phase 6t - 6) and wait for THEIR pieces of tile u before the barrier that ends
@@ -1693,13 +1455,12 @@ static int g_attn_gen = 7;
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
 static int g_wide6_min_items = 2048;
 void attn_set_wide_min(int items) { if (items > 0) g_wide6_min_items = items; }
-void attn_set_generation(int gen) { if (gen >= 1 && gen <= 10) g_attn_gen = gen; }
+void attn_set_generation(int gen) { if ((gen >= 1 && gen <= 7) || gen == 9) g_attn_gen = gen; }
 static int g_attn6_prio = 1;       // option "attn_prio": generation 9's s_setprio use (0 none | 1 matrix phase | 2 softmax phases)
 void attn_set_prio(int v) { if (v >= 0 && v <= 2) g_attn6_prio = v; }
 static int g_attn_stamps = 0;      // option "attn_stamps": generation 9 prints its per-phase s_memtime sums (timing experiments)
 void attn_set_stamps(int on) { g_attn_stamps = on; }
-static int g_attn5_stages = 4;     // LDS ring of the phased kernel (generation 8): 3 or 4 stages of 16 KiB
-void attn_set_stages(int r) { if (r == 3 || r == 4) g_attn5_stages = r; }
+
 // (the first-generation kernels -- attn_generation 1 and the attn_pipelined option -- scale the scores themselves and
 // reject a pre-scaled Q: producers must then leave q plain)
 float attn_q_scale(float scale) { return (g_attn_gen >= 2 && !g_attn_pipelined) ? scale * 1.4426950408889634f : 1.0f; }
@@ -1734,7 +1495,7 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         };
         int gen = g_attn_gen;
         if (gen == 7) gen = (g_attn_glds && count(256) >= g_wide6_min_items) ? 6 : 2;
-        const int qtile = (g_attn_glds && gen == 9) ? 384 : (g_attn_glds && gen >= 4 && gen != 10) ? 256 : 128;
+        const int qtile = (g_attn_glds && gen == 9) ? 384 : (g_attn_glds && gen >= 4) ? 256 : 128;
         const int items = count(qtile);
         if (gen == 9 && g_attn_glds) {     // phased 12-wave kernel (round 5): three groups, S1 | S2 | M
             const int prio = g_attn6_prio;
@@ -1769,18 +1530,6 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
             }
             return launch6(std::false_type{}, nullptr);
         }
-        if (gen == 8 && g_attn_glds) {     // phased 8-wave kernel (round 5): one workgroup per compute unit
-            static int state = 0;          // 0 unknown, 1 usable, -1 the device refuses the dynamic LDS size
-            if (state == 0) {
-                const bool a = hipFuncSetAttribute((const void*)attn5_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_B) == hipSuccess;
-                const bool b = hipFuncSetAttribute((const void*)attn5_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_B) == hipSuccess;
-                state = a && b ? 1 : -1;
-            }
-            if (state < 0) { (void)hipGetLastError(); return hipErrorNotSupported; }
-            if (g_attn5_stages == 3) hipLaunchKernelGGL((attn5_kernel<3>), dim3(items), dim3(512), 3 * STAGE_B, s, p);
-            else hipLaunchKernelGGL((attn5_kernel<4>), dim3(items), dim3(512), 4 * STAGE_B, s, p);
-            return hipGetLastError();
-        }
         if (g_attn_ablate && gen == 2) {
             switch (g_attn_ablate) {
 #define R3G_ABL2(m) case m: hipLaunchKernelGGL((attn2_kernel<true, false, 4, m>), dim3(items), dim3(256), 0, s, p); break;
@@ -1796,7 +1545,6 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         else if (gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 6) hipLaunchKernelGGL((attn3_kernel<4>), dim3(items), dim3(256), 0, s, p);
-        else if (gen == 10) hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 4>), dim3(items), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
         return hipGetLastError();
     }

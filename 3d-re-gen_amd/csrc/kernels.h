@@ -134,7 +134,6 @@ float attn_q_scale(float scale);
 void attn_set_wide_min(int items);     // generation 7: 256-query workgroups (generation 6) from this many work items on (default 2048)
 void attn_set_prio(int v);            // generation 9: 0 no s_setprio | 1 matrix phase raised | 2 softmax phases raised
 void attn_set_stamps(int on);         // generation 9: print per-phase s_memtime sums of every launch to stderr (timing experiments)
-void attn_set_stages(int r);          // generation 8 (phased 8-wave kernel): LDS ring of 3 | 4 (default) K / V^T stages
 void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
 void ln_set_rows4_min(int rows);     // automatic rule: launches of at least this many rows take 4 rows per wave (65536)
 void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave

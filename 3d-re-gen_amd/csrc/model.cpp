@@ -1323,7 +1323,6 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_pipelined")) attn_set_pipelined(value != 0);
     else if (!strcmp(name, "attn_ablate")) attn_set_ablate(value);
     else if (!strcmp(name, "attn_generation")) attn_set_generation(value);
-    else if (!strcmp(name, "attn_stages")) attn_set_stages(value);
     else if (!strcmp(name, "attn_stamps")) attn_set_stamps(value);
     else if (!strcmp(name, "attn_prio")) attn_set_prio(value);
     else if (!strcmp(name, "attn_wide_min")) attn_set_wide_min(value);

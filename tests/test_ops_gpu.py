@@ -190,11 +190,10 @@ def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, sh
     Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, shared, Lq + 3 * Lk)
     outs = []
     try:
-        # generations 8 / 9 (round 5): the phased 8-wave kernel (4- and 3-stage LDS ring) and the 12-wave one -- the same arithmetic in
+        # generation 9 (round 5): the phased 12-wave kernel (three groups one phase apart) -- the same arithmetic in
         # the same order per 32-query block, so the same bits
-        for gen, stages in ((2, 4), (6, 4), (8, 4), (8, 3), (9, 4)):
+        for gen in (2, 6, 9):
             ffi.check(L.r3g_set_option(b"attn_generation", gen))
-            ffi.check(L.r3g_set_option(b"attn_stages", stages))
             o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
             ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp,
                                          shared, 1, stream(torch)))
@@ -202,13 +201,12 @@ def test_attention_64_query_waves_match_the_default_kernel(env, B, H, Lq, Lk, sh
             outs.append(o)
     finally:
         ffi.check(L.r3g_set_option(b"attn_generation", 7))
-        ffi.check(L.r3g_set_option(b"attn_stages", 4))
     assert rel_l2(outs[1].float(), ref) <= 1e-2
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
 
 
-@pytest.mark.parametrize("gen", [2, 6, 8, 9])
+@pytest.mark.parametrize("gen", [2, 6, 9])
 def test_attention_ignores_stale_rows_past_lq(env, gen):
     """The query rows between Lq and the padded length hold whatever an earlier launch left there.  They are computed and
     dropped; they must not steer the wave-uniform re-stabilise branch either, or the rounding of the valid queries of
@@ -232,7 +230,7 @@ def test_attention_ignores_stale_rows_past_lq(env, gen):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("gen", [2, 6, 8, 9])
+@pytest.mark.parametrize("gen", [2, 6, 9])
 def test_attention_forced_rescale(env, gen):
     """One key row spiked against one query so the running max jumps late in the sequence
     (exercises the online-softmax rescale branch with a large factor)."""

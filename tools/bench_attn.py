@@ -31,10 +31,7 @@ def main():
     ap.add_argument("--gen", type=int, default=2, help="kernel generation the ablation masks apply to")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power sensitivity)")
     a = ap.parse_args()
-    # --gens entries: a generation, or "8:3" = generation 8 (the phased 8-wave kernel) with a 3-stage LDS ring (default 4)
-    def parse(m):
-        return int(m) if ":" not in m else int(m.split(":")[0]) * 100 + int(m.split(":")[1])
-    masks = [parse(m) for m in (a.gens or a.ablate).split(",")]
+    masks = [int(m) for m in (a.gens or a.ablate).split(",")]
     ffi.context(0)
     L = ffi.lib()
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -53,8 +50,7 @@ def main():
 
         def run(mask):
             if a.gens:
-                ffi.check(L.r3g_set_option(b"attn_generation", mask // 100 if mask >= 100 else mask))
-                ffi.check(L.r3g_set_option(b"attn_stages", mask % 100 if mask >= 100 else 4))
+                ffi.check(L.r3g_set_option(b"attn_generation", mask))
             else:
                 ffi.check(L.r3g_set_option(b"attn_ablate", mask))
             ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp,
