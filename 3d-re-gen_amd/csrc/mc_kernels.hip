@@ -23,7 +23,7 @@
 //                    compacted list of non-empty blocks.
 //   K3 mc_vertices : 1 thread per ACTIVE cell: fp64 interpolation, float32 store, edge->id table.
 //   K4 mc_faces    : 1 thread per ACTIVE cell: triangle corners -> ids (own rank or table lookup).
-//                    K3/K4 are launched over the non-empty blocks only.
+//                    K3/K4 are launched over the non-empty blocks only, 8 consecutive ones per 256-thread workgroup (24 measured slower: too few workgroups).
 // Only K1 touches the whole grid: algorithmic traffic = one grid read + one mesh write.
 //
 // Built with -ffp-contract=off: the ambiguity tests and interpolation must not be fused.
@@ -45,7 +45,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 1024;  // blocks per scan chunk
-constexpr int kEmitThreads = 64;  // K3 / K4: one wave per non-empty block
 
 __device__ __forceinline__ void cell_coords(uint32_t c, int cx, int cy, int& x, int& y, int& z) {
     const uint32_t row = c / (uint32_t)cx;
@@ -548,17 +547,62 @@ __global__ __launch_bounds__(kChunk) void mc_scan(const uint4* __restrict__ blk,
     }
 }
 
-__global__ __launch_bounds__(kEmitThreads) void mc_vertices(const float* __restrict__ grid, int nx, int ny, int cx, int cy,
+// K3 / K4 geometry (round 5): a workgroup of 256 threads takes kEmitGroup (8) CONSECUTIVE non-empty blocks and spreads their active
+// cells over its threads (a prefix over the blocks' active counts in LDS, a short linear search).  Rounds 1-4 gave every non-empty
+// block a 64-thread workgroup of its own: a block of a smooth surface holds ~11 active cells, so five lanes in six idled and an
+// object-sized mesh took 19 855 workgroups per kernel -- 45 + 25 us for 113 k vertices / 226 k faces (profiles/r05_mc_timeline.md).
+// Every output position comes from the scan (block offset + the record's in-block prefix), so the mesh is the same bit for bit.
+constexpr int kEmitGroup = 8;
+constexpr int kEmitWg = 256;
+
+// the calling thread's (block, index of an active cell in it) for item `i` of the workgroup's cells, or false when i is past them
+struct EmitMap {
+    unsigned pre[kEmitGroup + 1];
+    uint32_t blk_id[kEmitGroup];
+};
+__device__ __forceinline__ void emit_map_build(EmitMap* m, const uint4* __restrict__ blk, const uint32_t* __restrict__ nzlist,
+                                               uint32_t nnz) {
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+#pragma unroll
+        for (int j = 0; j < kEmitGroup; ++j) {
+            const uint32_t g = blockIdx.x * kEmitGroup + j;
+            m->pre[j] = run;
+            if (g < nnz) {
+                const uint32_t b = nzlist[g];
+                m->blk_id[j] = b;
+                run += blk[b].z;
+            } else {
+                m->blk_id[j] = 0;
+            }
+        }
+        m->pre[kEmitGroup] = run;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool emit_map_find(const EmitMap* m, unsigned i, uint32_t* b, unsigned* local) {
+    if (i >= m->pre[kEmitGroup]) return false;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kEmitGroup; ++k) j += (i >= m->pre[k]) ? 1 : 0;
+    *b = m->blk_id[j];
+    *local = i - m->pre[j];
+    return true;
+}
+
+__global__ __launch_bounds__(kEmitWg) void mc_vertices(const float* __restrict__ grid, int nx, int ny, int cx, int cy,
                                                       double level, const uint2* __restrict__ act,
                                                       const uint4* __restrict__ blk, const uint2* __restrict__ blkoff,
-                                                      const uint32_t* __restrict__ nzlist,
+                                                      const uint32_t* __restrict__ nzlist, uint32_t nnz,
                                                       int32_t* __restrict__ etab, float* __restrict__ verts,
                                                       Xform xf, int use_xf) {
-    // one wave per non-empty block: a block of 256 cells holds ~10-30 active cells (at most 256: the loop)
-    const uint32_t b = nzlist[blockIdx.x];
-    const unsigned n_act = blk[b].z;
-    const uint32_t voff = blkoff[b].x;
-    for (unsigned tid = threadIdx.x; tid < n_act; tid += kEmitThreads) {
+    __shared__ EmitMap map;
+    emit_map_build(&map, blk, nzlist, nnz);
+    for (unsigned i = threadIdx.x;; i += kEmitWg) {
+        uint32_t b;
+        unsigned tid;
+        if (!emit_map_find(&map, i, &b, &tid)) break;
+        const uint32_t voff = blkoff[b].x;
         const uint2 a = act[(size_t)b * kBlock + tid];
         const uint32_t c = b * kBlock + (a.y & 0xFFu);
         int x, y, z;
@@ -567,15 +611,18 @@ __global__ __launch_bounds__(kEmitThreads) void mc_vertices(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(kEmitThreads) void mc_faces(int nx, int ny, int cx, int cy, const uint2* __restrict__ act,
+__global__ __launch_bounds__(kEmitWg) void mc_faces(int nx, int ny, int cx, int cy, const uint2* __restrict__ act,
                                                    const uint4* __restrict__ blk, const uint2* __restrict__ blkoff,
-                                                   const uint32_t* __restrict__ nzlist,
+                                                   const uint32_t* __restrict__ nzlist, uint32_t nnz,
                                                    const int32_t* __restrict__ etab, int32_t* __restrict__ faces,
                                                    int reversed) {
-    const uint32_t b = nzlist[blockIdx.x];
-    const unsigned n_act = blk[b].z;
-    const uint2 off = blkoff[b];
-    for (unsigned tid = threadIdx.x; tid < n_act; tid += kEmitThreads) {
+    __shared__ EmitMap map;
+    emit_map_build(&map, blk, nzlist, nnz);
+    for (unsigned i = threadIdx.x;; i += kEmitWg) {
+        uint32_t b;
+        unsigned tid;
+        if (!emit_map_find(&map, i, &b, &tid)) break;
+        const uint2 off = blkoff[b];
         const uint2 a = act[(size_t)b * kBlock + tid];
         const uint32_t c = b * kBlock + (a.y & 0xFFu);
         int x, y, z;
@@ -671,12 +718,13 @@ hipError_t mc_emit_launch(const float* grid, int n0, int n1, int n2, double leve
     }
     ProfScope ps(PC_MC_OTHER, 0.0, stream);
     const uint32_t* nz = (const uint32_t*)(ws + lay.off_nz);
-    hipLaunchKernelGGL(mc_vertices, dim3(lay.nnz), dim3(kEmitThreads), 0, stream, grid, nx, ny, cx, cy, level,
+    const uint32_t wgs = (lay.nnz + kEmitGroup - 1) / kEmitGroup;
+    hipLaunchKernelGGL(mc_vertices, dim3(wgs), dim3(kEmitWg), 0, stream, grid, nx, ny, cx, cy, level,
                        (const uint2*)(ws + lay.off_act), (const uint4*)(ws + lay.off_blk),
-                       (const uint2*)(ws + lay.off_blkoff), nz, (int32_t*)(ws + lay.off_etab), verts, xf, xf9 ? 1 : 0);
-    hipLaunchKernelGGL(mc_faces, dim3(lay.nnz), dim3(kEmitThreads), 0, stream, nx, ny, cx, cy,
+                       (const uint2*)(ws + lay.off_blkoff), nz, (uint32_t)lay.nnz, (int32_t*)(ws + lay.off_etab), verts, xf, xf9 ? 1 : 0);
+    hipLaunchKernelGGL(mc_faces, dim3(wgs), dim3(kEmitWg), 0, stream, nx, ny, cx, cy,
                        (const uint2*)(ws + lay.off_act), (const uint4*)(ws + lay.off_blk),
-                       (const uint2*)(ws + lay.off_blkoff), nz, (const int32_t*)(ws + lay.off_etab), faces, reversed);
+                       (const uint2*)(ws + lay.off_blkoff), nz, (uint32_t)lay.nnz, (const int32_t*)(ws + lay.off_etab), faces, reversed);
     return hipGetLastError();
 }
 

@@ -29,6 +29,22 @@ for l in open("$O/r05_attn_gens.jsonl"):
 PY
     tail -3 $O/r05_attn_gens.err
     ;;
+mc)
+    # per-launch timeline of one marching-cubes call on the object-like field and on a noise field
+    R=$(pwd)
+    for f in blob noise; do
+        timeout 120 python tools/bench_mc.py --field $f --iters 20 > $O/r05_mc_bench_$f.json 2>/dev/null
+        (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace -d $R/$O/r05_mc_trace_$f -o t -- python $R/tools/bench_mc.py --field $f --iters 5 > $R/$O/r05_mc_trace_$f.log 2>&1)
+        DB=$(ls $O/r05_mc_trace_$f/*/*_results.db $O/r05_mc_trace_$f/*_results.db 2>/dev/null | head -1)
+        python tools/mc_timeline.py $DB "marching cubes on the 257^3 '$f' field: one call" > $O/r05_mc_timeline_$f.md
+        cat $O/r05_mc_bench_$f.json | cut -c1-500; cat $O/r05_mc_timeline_$f.md
+        rm -rf $O/r05_mc_trace_$f
+    done
+    ;;
+tex)
+    timeout 600 python -m pytest tests/test_unet_gpu.py tests/test_aekl_gpu.py tests/test_unet2p5d_gpu.py -m gpu -q -x 2>&1 | tail -4
+    timeout 600 python tests/tex_stage_time.py > $O/r05_texture_stage_time.json 2> $O/r05_texture_stage_time.err; tail -3 $O/r05_texture_stage_time.json | cut -c1-600
+    ;;
 newtests)
     timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_nccl_one_rank_gpu.py tests/test_reference_script_gpu.py \
         "tests/test_model_gpu.py::test_fp16_stream_overflow_runs_the_group_again_on_the_fp32_stream" \
