@@ -1577,6 +1577,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         if (wr == 0) R3G_BAR();
 
         const Tile done = cur;
+        // Round 5: the lane number the epilogue works with is made opaque once per tile.  Everything the epilogue derives from it
+        // (store addresses, row maps, LDS offsets) is invariant across the tiles of a workgroup; left visible, the compiler
+        // hoists it all out of the tile loop and spills it around the k-loop (2-3 registers for the bf16 epilogues, 13 for the
+        // fp32 residual one, 32 for the fused QKV one -- round 4 read those spills as a cost of the persistent form itself).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
         // the finished tile's bias goes first: a wait for it must not also wait for the LDS-DMA issued below (vmcnt is in
         // order), and its latency hides under the staging (s_memtime: epilogue 10.4 k -> 8.5 k cycles)
         f32x4 bias_pre[4];
@@ -1584,7 +1590,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
             const GemmArgs& pp = args_of(done.second);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = done.n0 + wc * 64 + ((lane >> 4) << 2) + j * 16;
+                const int n = done.n0 + wc * 64 + ((lane_e >> 4) << 2) + j * 16;
                 bias_pre[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (pp.bias) bias_pre[j] = *reinterpret_cast<const f32x4*>(pp.bias + (n < pp.N ? n : pp.N - 4));
             }
@@ -1599,7 +1605,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         }
         {
             const GemmArgs& pp = args_of(done.second);
-            gemm_epilogue<EPI, MI, true, 2, EARLY>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane,
+            gemm_epilogue<EPI, MI, true, 2, EARLY>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
                                                    pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr,
                                                    (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) ? bias_pre : nullptr);
             // (last tile: no next k-tile was staged, the wait inside the epilogue found nothing -- harmless)
