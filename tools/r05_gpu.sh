@@ -7,7 +7,7 @@
 #   ab <opts_a> <opts_b> [steps] [warmup]   bench.py A/B/A/B with R3G_OPTIONS=<opts_a> / <opts_b> ("-" = no options)
 #   suite      the whole -m gpu suite
 #   bench      the driver's invocation of bench.py
-#   evidence <commit> [objects per launch]  kernel trace + PMC passes (tools/r04_profile.sh does the work; files renamed to r05)
+#   evidence <commit> [objects per launch]  kernel trace + PMC passes (tools/profile_evidence.sh), tables -> gpurun_out/r05_*.md
 set -x
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -76,7 +76,7 @@ bench)
     cut -c1-600 $O/r05_bench.json; tail -2 $O/r05_bench.err
     ;;
 evidence)
-    bash tools/r04_profile.sh "$2" "${3:-4}"
+    bash tools/profile_evidence.sh "$2" "${3:-4}" r05
     ;;
 *)
     echo "unknown step $1"; exit 2;;

@@ -24,6 +24,11 @@ __global__ void k(unsigned long long* out, float* sink, int iters, float seed) {
             if (KIND == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (KIND == 7) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(a[(i + 2) & 15]));
             if (KIND == 8) asm volatile("v_fma_mix_f32 %0, %0, %1, 0 op_sel_hi:[0,1,0]" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+            if (KIND == 10) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
+            if (KIND == 11) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+            if (KIND == 12) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+            if (KIND == 13) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+            if (KIND == 14) asm volatile("v_exp_f16_e64 %0, %0" : "+v"(a[i]));
             if (KIND == 9 && i < 8) asm volatile("s_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
         }
     }
@@ -61,6 +66,11 @@ int main() {
     run<8>("v_fma_mix_f32", 16);
     run<0>("v_exp_f32", 16);
     run<6>("v_rcp_f32", 16);
+    run<10>("v_exp_f16", 16);
+    run<14>("v_exp_f16 hi->hi", 16);
+    run<11>("v_pk_max_f16", 16);
+    run<12>("v_pk_add_f16", 16);
+    run<13>("v_cvt_pk_f16_f32", 16);
     run<9>("v_permlane32_swap", 8);
     return 0;
 }
