@@ -54,42 +54,84 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restri
     *reinterpret_cast<uint4*>(out + m * (9 * (int64_t)C) + (int64_t)tap * C + c8 * 8) = v;
 }
 
-// ---- GroupNorm, pass 1: block b sums rows [b*rpb, (b+1)*rpb) per channel (thread t owns channels t, t + 256, ...), folds
-// the channels of a group in LDS and writes (sum, sum of squares) per group as fp64 to partial[b][g][2]
+// ---- GroupNorm, pass 1: block b sums rows [b*rpb, (b+1)*rpb) per channel, folds the channels of a group in LDS and writes
+// (sum, sum of squares) per group as fp64 to partial[b][g][2]
 constexpr int GN_MAX_CPT = 12;   // channels per thread: C <= 3072 (the up blocks normalise cat(hidden, skip): 2560 channels)
 // Round 4: all samples of a call in ONE launch (blockIdx.y = sample; x and partial advance by a sample): the six views of the
 // multiview UNet used to be 6 x 2 launches of a few microseconds of work each -- GroupNorm was 39 % of the texture step's kernel
 // time (profiles/r04_texture_stage.md).
+// Round 5: float4 columns instead of scalar channels (thread = (row lane p, column q) with 256 / (C / 4) row lanes when C <= 1024,
+// up to three columns per thread above), four rows' loads in flight, and the groups folded by 256 / groups lanes each -- the
+// round-4 kernel took 28 us for 64 rows and 43 us for 6 x 4096 rows x 320 channels (31 MB), 10.7 % of the texture step's kernel
+// time (profiles/r05_texture_stage.md).  Every sum keeps a fixed order: rows ascending per (p, channel); per group lane j adds
+// its items j, j + L, ... (item = channel-major, then row lane), then a fixed xor tree over the L lanes.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int C, int groups, int rpb,
                                                          double* __restrict__ partial) {
-    __shared__ float s_sum[256 * GN_MAX_CPT], s_sq[256 * GN_MAX_CPT];
+    __shared__ float s_sum[256 * GN_MAX_CPT], s_sq[256 * GN_MAX_CPT];     // [row lane][C], P * C <= max(1024, C)
+    constexpr int NQ = GN_MAX_CPT / 4;
     const int t = threadIdx.x;
     x += (int64_t)blockIdx.y * rows * C;
     partial += (int64_t)blockIdx.y * gridDim.x * groups * 2;
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
-    float a[GN_MAX_CPT], q[GN_MAX_CPT];
+    const int cq = C >> 2;
+    const int P = cq >= 256 ? 1 : 256 / cq;          // row lanes
+    const int p = cq >= 256 ? 0 : t / cq;
+    const int q0 = cq >= 256 ? t : t - p * cq;
+    const bool active = p < P;
+    float4 a[NQ], sq[NQ];
 #pragma unroll
-    for (int k = 0; k < GN_MAX_CPT; ++k) { a[k] = 0.f; q[k] = 0.f; }
-    for (int r = r0; r < r1; ++r) {
-        const float* row = x + (int64_t)r * C;
+    for (int k = 0; k < NQ; ++k) { a[k] = make_float4(0.f, 0.f, 0.f, 0.f); sq[k] = a[k]; }
+    auto add = [](float4& acc, float4& acc2, const float4& v) {
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        acc2.x += v.x * v.x; acc2.y += v.y * v.y; acc2.z += v.z * v.z; acc2.w += v.w * v.w;
+    };
+    if (active) {
 #pragma unroll
-        for (int k = 0; k < GN_MAX_CPT; ++k) {
-            const int c = t + k * 256;
-            if (c < C) { const float v = row[c]; a[k] += v; q[k] += v * v; }
+        for (int k = 0; k < NQ; ++k) {
+            const int q = q0 + k * 256;
+            if (q < cq) {
+                const float* col = x + (int64_t)q * 4;
+                int r = r0 + p;
+                for (; r + 3 * P < r1; r += 4 * P) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(col + (int64_t)(r + u * P) * C);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) add(a[k], sq[k], v[u]);
+                }
+                for (; r < r1; r += P) add(a[k], sq[k], *reinterpret_cast<const float4*>(col + (int64_t)r * C));
+            }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < GN_MAX_CPT; ++k) {
-        const int c = t + k * 256;
-        if (c < C) { s_sum[c] = a[k]; s_sq[c] = q[k]; }
+        for (int k = 0; k < NQ; ++k) {
+            const int q = q0 + k * 256;
+            if (q < cq) {
+                *reinterpret_cast<float4*>(s_sum + (int64_t)p * C + q * 4) = a[k];
+                *reinterpret_cast<float4*>(s_sq + (int64_t)p * C + q * 4) = sq[k];
+            }
+        }
     }
     __syncthreads();
     const int cpg = C / groups;
-    for (int g = t; g < groups; g += 256) {
-        double s = 0.0, ss = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)s_sum[c]; ss += (double)s_sq[c]; }
-        partial[((int64_t)blockIdx.x * groups + g) * 2] = s;
-        partial[((int64_t)blockIdx.x * groups + g) * 2 + 1] = ss;
+    int L = 1;                                        // lanes per group: a power of two, L * groups <= 256, L <= 8
+    while (L < 8 && 2 * L * groups <= 256) L *= 2;
+    const int g = t / L, j = t - g * L;
+    double sd = 0.0, ssd = 0.0;
+    if (g < groups) {
+        const int items = cpg * P;
+        for (int it = j; it < items; it += L) {
+            const int c = g * cpg + it / P, pp = it - (it / P) * P;
+            sd += (double)s_sum[pp * C + c];
+            ssd += (double)s_sq[pp * C + c];
+        }
+    }
+    for (int d = L >> 1; d >= 1; d >>= 1) {
+        sd += __shfl_xor(sd, d, 64);
+        ssd += __shfl_xor(ssd, d, 64);
+    }
+    if (g < groups && j == 0) {
+        partial[((int64_t)blockIdx.x * groups + g) * 2] = sd;
+        partial[((int64_t)blockIdx.x * groups + g) * 2 + 1] = ssd;
     }
 }
 
@@ -140,25 +182,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
     __syncthreads();
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
-    const int c4n = C >> 2;
-    for (int64_t i = (int64_t)r0 * c4n + t; i < (int64_t)r1 * c4n; i += 256) {
-        const int c = (int)(i % c4n) * 4;
-        const int64_t r = i / c4n;
-        const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+    // thread = (row lane p, float4 column q) as in pass 1: the column's gamma / beta / mean / rstd live in registers, four rows'
+    // loads are in flight, no division in the loop (round 5; the arithmetic per element is round 4's, bit for bit)
+    const int cq = C >> 2;
+    const int P = cq >= 256 ? 1 : 256 / cq;
+    const int p = cq >= 256 ? 0 : t / cq;
+    const int q0 = cq >= 256 ? t : t - p * cq;
+    if (p >= P) return;
+    for (int q = q0; q < cq; q += 256) {
+        const int c = q * 4;
         const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
         const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-        const float in[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gm.x, gm.y, gm.z, gm.w}, bw[4] = {bt.x, bt.y, bt.z, bt.w};
-        float o[4];
+        const float gw[4] = {gm.x, gm.y, gm.z, gm.w}, bw[4] = {bt.x, bt.y, bt.z, bt.w};
+        float mu[4], rs[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int g = (c + e) / cpg;
-            const float z = (in[e] - s_mean[g]) * s_rstd[g] * gw[e] + bw[e];
-            o[e] = do_silu ? silu(z) : z;
+            mu[e] = s_mean[g];
+            rs[e] = s_rstd[g];
         }
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-        *reinterpret_cast<uint2*>(y + r * C + c) = pk;
+        auto emit = [&](int64_t r, const float4& v) {
+            const float in[4] = {v.x, v.y, v.z, v.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = (in[e] - mu[e]) * rs[e] * gw[e] + bw[e];
+                o[e] = do_silu ? silu(z) : z;
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+            pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+            *reinterpret_cast<uint2*>(y + r * C + c) = pk;
+        };
+        int r = r0 + p;
+        for (; r + 3 * P < r1; r += 4 * P) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(r + u * P) * C + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(r + u * P, v[u]);
+        }
+        for (; r < r1; r += P) emit(r, *reinterpret_cast<const float4*>(x + (int64_t)r * C + c));
     }
 }
 

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs pa, GemmArgs pb)
     const int tm = rowi - batch * tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const uint16_t* A = p.A + (int64_t)batch * p.strideA;
-    const uint16_t* W = p.W;
+    const uint16_t* W = p.W + (int64_t)batch * p.strideW;
     const int wr = wid / WN, wc = wid % WN;
 
     f32x4 acc[4][MI];  // [j: n sub-tile][i: m sub-tile]
@@ -1741,6 +1741,58 @@ hipError_t launch_cfg(const GemmArgs& p, const GemmArgs& p2, bool glds, hipStrea
     return hipGetLastError();
 }
 
+// ---- split-K of the 128x128 kernel (round 5): the texture UNets' 3 x 3 convolutions at the coarse levels are GEMMs of a few
+// hundred rows over K = 9 Cin up to 23 040 -- 10 to 240 tiles on a chip that holds 512 of these workgroups, each walking 180 to
+// 360 k-steps alone (118 / 235 us at 64 ... 384 rows x 1280 columns, profiles/r05_gemm_splitk.md).  S slices of K run as the
+// S batches of ONE ordinary EPI_F32 launch (strideA = strideW = K / S along the rows' k axis) into the caller's workspace
+// [S][M][N]; this kernel adds the slices in the order s = 0 .. S-1 and applies bias / gate / residual as the fused epilogues do.
+// Deterministic: no atomics, the order of the additions is fixed by (M, N, K) alone.
+template <bool RESID>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int64_t MN, int N,
+                                                            const float* __restrict__ bias, const float* __restrict__ gate,
+                                                            float* __restrict__ C, int64_t ldc) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + i);
+    int s = 1;
+    for (; s + 4 <= S; s += 4) {
+        f32x4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const f32x4*>(ws + (int64_t)(s + k) * MN + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += t[k];
+    }
+    for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (int64_t)s * MN + i);
+    const int64_t m = i / N;
+    const int n = (int)(i - m * N);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+    float* dst = C + m * ldc + n;
+    if (RESID) {
+        if (gate) v = *reinterpret_cast<const f32x4*>(gate + n) * v;
+        v = *reinterpret_cast<const f32x4*>(dst) + v;
+    }
+    *reinterpret_cast<f32x4*>(dst) = v;
+}
+
+bool g_gemm_splitk128 = true;
+constexpr int kSplit128Slots = 512;    // 128x128 workgroups the chip holds at once (2 per CU)
+constexpr int kSplit128MinSteps = 8;   // k-steps of 64 a slice keeps at least
+
+// number of slices: the largest divisor S of K / 64 with S * tiles <= 512 slots and >= 8 k-steps per slice (1: no split)
+static int splitk128_factor(int M, int N, int K, int num_cu) {
+    if (K < 2048 || K % 64) return 1;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long slots = (long)kSplit128Slots * num_cu / 256;
+    if (tiles * 2 > slots) return 1;
+    const int nk = K / 64;
+    int best = 1;
+    for (int S = 2; S <= 64 && S * tiles <= slots && nk / S >= kSplit128MinSteps; ++S)
+        if (nk % S == 0) best = S;
+    // two slices save half of a short k-loop and pay a pass over the output for it: measured a loss at K = 2560, a gain from 5760
+    if (best == 2 && K < 4096) best = 1;
+    return best;
+}
+
 static int g_gemm_waves = 0;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 2, g_num_cu = 256;
@@ -1836,6 +1888,8 @@ void gemm_set_phased(bool on) { g_gemm_phased = on; }
 void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
+void gemm_set_splitk128(bool on) { g_gemm_splitk128 = on; }
+int gemm_splitk128_factor(int M, int N, int K) { return splitk128_factor(M, N, K, g_num_cu); }
 void gemm_set_early_wait(bool on) { g_gemm_early_wait = on; }
 void gemm_set_persistent_qkv(bool on) { g_gemm_persistent_qkv = on; }
 void gemm_set_config(int waves) {
@@ -1885,6 +1939,35 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
                  alg_bytes(p) + alg_bytes(p2));
+    if (p.split_ws && g_gemm_splitk128 && g_gemm_waves == 0 && p2.M == 0 && batch == 1 && (p.epi == EPI_F32 || p.epi == EPI_RESID_F32) &&
+        (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
+        const int S = splitk128_factor(p.M, p.N, p.K, g_num_cu);
+        const int64_t MN = (int64_t)p.M * p.N;
+        if (S > 1 && (int64_t)S * MN <= p.split_ws_elems) {
+            GemmArgs q = p;
+            q.K = p.K / S;
+            q.batch = S;
+            q.strideA = q.K;
+            q.strideW = q.K;
+            q.bias = nullptr;
+            q.gate = nullptr;
+            q.C = p.split_ws;
+            q.ldc = p.N;
+            q.strideC = MN;
+            q.epi = EPI_F32;
+            q.split_ws = nullptr;
+            const hipError_t e = launch_cfg<EPI_F32, 8, 0>(q, GemmArgs{}, g_gemm_glds, s);
+            if (e != hipSuccess) return e;
+            const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
+            if (p.epi == EPI_RESID_F32)
+                hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, (const float*)p.split_ws, S, MN, p.N,
+                                   p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
+            else
+                hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float*)p.split_ws, S, MN, p.N,
+                                   p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
+            return hipGetLastError();
+        }
+    }
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, p2, g_gemm_glds, s);
         case EPI_BF16_GELU_TANH: return launch_epi<EPI_BF16_GELU_TANH>(p, p2, g_gemm_glds, s);

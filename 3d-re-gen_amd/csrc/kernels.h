@@ -62,6 +62,7 @@ struct GemmArgs {
     int64_t lda, strideA;
     const uint16_t* W;  // bf16 [N][K], row stride ldw
     int64_t ldw;
+    int64_t strideW;    // batch stride of W (elements): only the 128x128 kernel reads it (split-K: the batches are slices of K); 0 = shared
     const float* bias;  // [N] or null
     void* C;            // bf16 or f32 [batch][M][N], row stride ldc, batch stride strideC (elements)
     int64_t ldc, strideC;
@@ -76,6 +77,10 @@ struct GemmArgs {
     int raster_group;   // tile columns per rasterisation group (0 = row-major), filled in by gemm_launch
     int gelu_pk;        // 1: GELU epilogues in packed fp16 (gemm_common.h), filled in by gemm_launch
     QkvEpi qkv;         // EPI_QKV only (N % 64 == 0)
+    // deterministic split-K for the fp32 epilogues (EPI_F32, EPI_RESID_F32) of ONE under-filled deep-K problem (the texture UNets'
+    // 3 x 3 convolutions at the coarse levels): the caller's workspace for the partial products, null = never split
+    float* split_ws;
+    int64_t split_ws_elems;
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
@@ -90,6 +95,8 @@ void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default off: measured slower)
 void gemm_set_early_wait(bool on);   // persistent phased kernel: the next tile's first k-tile is waited for inside the epilogue (default off: no effect)
+void gemm_set_splitk128(bool on);    // split-K of the 128x128 kernel where GemmArgs::split_ws allows it (default on)
+int gemm_splitk128_factor(int M, int N, int K);   // the number of K slices the rule picks for one problem (1 = no split)
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs
 void gemm_set_persistent_resid(int mask);   // persistent form also for the fp32 (bit 0) / bf16 (bit 1) residual epilogues
 void gemm_set_persistent(bool on);   // phased kernel walks several tiles per workgroup (default on)

@@ -1239,6 +1239,24 @@ int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t l
     return R3G_OK;
 }
 
+int r3g_op_gemm_splitk(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, float* d_c, int64_t ldc,
+                       const float* d_gate, int m_, int n_, int k_, int epilogue, float* d_ws, int64_t ws_elems, int* slices,
+                       void* stream) {
+    if (epilogue != EPI_F32 && epilogue != EPI_RESID_F32) return fail(R3G_ERR_INVALID, "r3g_op_gemm_splitk: fp32 epilogues (3, 4) only");
+    if (!d_ws || ws_elems < 1) return fail(R3G_ERR_INVALID, "r3g_op_gemm_splitk: no workspace");
+    GemmArgs p{};
+    p.A = d_a; p.lda = lda; p.W = d_w; p.ldw = ldw; p.bias = d_bias; p.C = d_c; p.ldc = ldc; p.gate = d_gate;
+    p.M = m_; p.N = n_; p.K = k_; p.epi = epilogue;
+    p.split_ws = d_ws; p.split_ws_elems = ws_elems;
+    if (slices) {
+        const int S = gemm_splitk128_factor(m_, n_, k_);
+        *slices = (int64_t)S * m_ * n_ <= ws_elems ? S : 1;
+    }
+    hipError_t e = gemm_launch(p, 1, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "r3g_op_gemm_splitk");
+    return R3G_OK;
+}
+
 int r3g_op_quant_fp8(const uint16_t* d_x, int64_t ldx, int rows, int k_, uint8_t* d_q, int64_t ldq, float* d_scale, void* stream) {
     if (!d_x || !d_q || !d_scale) return fail(R3G_ERR_INVALID, "r3g_op_quant_fp8: null argument");
     hipError_t e = quant_fp8_rows_launch(d_x, ldx, rows, k_, d_q, ldq, d_scale, (hipStream_t)stream);
@@ -1316,6 +1334,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_persistent")) gemm_set_persistent(value != 0);
     else if (!strcmp(name, "gemm_persistent_resid")) gemm_set_persistent_resid(value);
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
+    else if (!strcmp(name, "gemm_splitk128")) gemm_set_splitk128(value != 0);
     else if (!strcmp(name, "gemm_early_wait")) gemm_set_early_wait(value != 0);
     else if (!strcmp(name, "gemm_persistent_qkv")) gemm_set_persistent_qkv(value != 0);
     else if (!strcmp(name, "flow_first_step")) g_flow_first_step = value;

@@ -50,6 +50,7 @@ struct Unet {
     uint16_t *ctxK = nullptr, *ctxVt = nullptr;
     float *vec = nullptr;                  // [4][max_channels] small vectors
     double* gn_partial = nullptr;
+    float* splitws = nullptr;              // split-K workspace of the 3 x 3 convolutions (kSplitWsElems floats, GemmArgs::split_ws)
     // whole-model forward (r3g_unet_forward): the concatenated input of an up-block resnet, two hidden-state buffers, the
     // time embedding, and the stack of skip connections (allocated on first use for the resolution at hand)
     float *catbuf = nullptr, *hb[2] = {nullptr, nullptr}, *emb = nullptr;
@@ -68,6 +69,7 @@ struct Unet {
     float mva_scale = 1.0f, ref_scale = 1.0f;
 };
 constexpr int kMaxViews = 16;
+constexpr int64_t kSplitWsElems = 512LL * 128 * 128;   // slices x tiles <= 512 workgroups of 128 x 128 (gemm.hip: splitk128_factor)
 
 #define U_TRY(expr)                                            \
     do {                                                       \
@@ -117,10 +119,11 @@ static int u_vec(const Unet& u, const std::string& name, int n, const float** ou
 }
 
 static int u_gemm(const uint16_t* A, int64_t lda, const ULin& l, const float* bias, void* C, int64_t ldc, int M, int epi,
-                  hipStream_t s) {
+                  hipStream_t s, float* split_ws = nullptr) {
     GemmArgs p{};
     p.A = A; p.lda = lda; p.W = l.w; p.ldw = l.K; p.bias = bias; p.C = C; p.ldc = ldc;
     p.M = M; p.N = l.N; p.K = l.K; p.epi = epi;
+    p.split_ws = split_ws; p.split_ws_elems = split_ws ? kSplitWsElems : 0;
     hipError_t e = gemm_launch(p, 1, s);
     if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet)");
     return R3G_OK;
@@ -140,7 +143,8 @@ static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int st
                      int epi, hipStream_t s, int pad = 1, int nb = 1) {
     const int Ho = (H + pad - 2) / stride + 1, Wo = (W + pad - 2) / stride + 1;
     U_TRY(im2col3x3_launch(src, H, W, Cin, stride, pad, u.col, s, nb));       // every sample of the call in one launch
-    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, nb * Ho * Wo, epi, s);
+    // few rows over a deep K (the coarse levels): slices of K side by side, summed in a fixed order (gemm.hip: split-K of the 128x128 kernel)
+    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, nb * Ho * Wo, epi, s, u.splitws);
 }
 
 // GroupNorm (+ SiLU) per sample of f32 rows [nb][hw][C] -> bf16
@@ -690,7 +694,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
                  o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
                  o_gn = carve((int64_t)kMaxViews * (256LL * 256 * 2 * 8 + 256 * 2 * 4)), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
                  o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4), o_vecn = carve((int64_t)kMaxViews * C * 4),
-                 o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4);
+                 o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4), o_split = carve(kSplitWsElems * 4);
     hipError_t e = hipMalloc((void**)&u->arena, off);
     if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMalloc(unet arena)"); }
     e = hipMemset(u->arena, 0, off);      // padded rows must start finite
@@ -702,6 +706,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     u->vec = (float*)(a + o_vec); u->gn_partial = (double*)(a + o_gn);
     u->catbuf = (float*)(a + o_cat); u->hb[0] = (float*)(a + o_hb0); u->hb[1] = (float*)(a + o_hb1); u->emb = (float*)(a + o_emb);
     u->vecn = (float*)(a + o_vecn); u->embn = (float*)(a + o_embn); u->gate = (float*)(a + o_gate);
+    u->splitws = (float*)(a + o_split);
     ctx->unet = u;
     return R3G_OK;
 }

@@ -76,6 +76,7 @@ SYMBOLS = {
     "r3g_sched_cfg_combine": (_I, [_P, _P, ctypes.c_int64, ctypes.c_float, _P, _P]),
     "r3g_sched_euler_ancestral_step": (_I, [_P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, _I, _P]),
     "r3g_op_gemm": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _I, _P]),
+    "r3g_op_gemm_splitk": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "r3g_op_quant_fp8": (_I, [_P, ctypes.c_int64, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "r3g_op_gemm_fp8": (_I, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P, _P, ctypes.c_int64, _P, _I, _I, _I, _I, _P]),
     "r3g_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

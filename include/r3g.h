@@ -351,6 +351,14 @@ int r3g_sched_euler_ancestral_step(float* d_sample, const float* d_model_out, co
  * 3 f32 C += gate*(..), 4 f32.  k % 64 == 0, n % 4 == 0. */
 int r3g_op_gemm(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, void* d_c,
                 int64_t ldc, const float* d_gate, int m, int n, int k, int epilogue, int use_lds_dma, void* stream);
+/* r3g_op_gemm for the fp32 epilogues (3, 4) with the caller's split-K workspace d_ws (ws_elems floats), as the texture UNets' 3 x 3
+ * convolutions launch it (csrc/unet.cpp: u_conv3x3): a problem of at most 256 tiles of 128 x 128 with k >= 2048 runs as S slices of k
+ * -- the S batches of one launch of the 128 x 128 kernel into d_ws [S][m][n] -- that a second kernel adds in the order 0 .. S-1
+ * before bias / gate / residual (S = the largest divisor of k / 64 with S * tiles <= 512 and >= 8 k-steps per slice; two slices only from k = 4096).  No atomics:
+ * the result is a pure function of the operands and (m, n, k).  *slices (may be null) = S, 1 = the ordinary launch. */
+int r3g_op_gemm_splitk(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, int64_t ldw, const float* d_bias, float* d_c, int64_t ldc,
+                       const float* d_gate, int m, int n, int k, int epilogue, float* d_ws, int64_t ws_elems, int* slices,
+                       void* stream);
 /* softmax(Q K^T / 8) V for head_dim 64: Q bf16 [B][H][lq_pad][64] (plain q: this entry point folds the softmax scale
  * in itself), K bf16 [B][H][lk_pad][64], Vt bf16 [B][H][64][lk_pad] -> O bf16 [B][lq][H*64].
  * Vt holds V transposed with the keys of each row in the kernel's operand order: inside every aligned group of 16 keys
@@ -392,7 +400,9 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
- * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "geo_q_cache_gb" (the
+ * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "gemm_splitk128" (1 default: the 3 x 3 convolutions of the texture models split a deep k over
+ * several workgroups where their grid would fill less than half of the chip, r3g_op_gemm_splitk | 0: one workgroup per tile walks all of k, rounds 2-4 -- another
+ * order of the fp32 additions, not bit-preserving), "geo_q_cache_gb" (the
  * budget of geo_q_cache in GiB; < 0, the default: 30 % of the device's memory; a grid that needs more gets a prefix of its passes
  * cached), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
  * activation type -- | 0: in fp32, rounds 1-3; NOT bit-preserving: 50-step latents at full depth 3.3e-3 against 3.0e-3 from the

@@ -134,6 +134,58 @@ def test_gemm_split_k_is_correct_and_deterministic(env, epi, M, N, K):
     assert rel_l2(outs[0].float(), want) <= 5e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi,slices", [(384, 1280, 11520, 4, 15), (64, 1280, 23040, 3, 45), (1000, 320, 2880, 4, 5),
+                                              (4096, 320, 5760, 3, 5), (1537, 644, 5760, 4, 6), (24576, 320, 2880, 4, 1),
+                                              (300, 256, 1024, 3, 1)])
+def test_gemm_split_k_of_the_convolutions(env, M, N, K, epi, slices):
+    """r3g_op_gemm_splitk, the launch of the texture UNets' 3 x 3 convolutions: few tiles over a deep k run as slices of k into a
+    workspace, added in a fixed order.  The slice count is the stated rule's; the result is the unsplit kernel's up to the order of
+    fp32 additions, the same bits on every run, and nothing is written past [m][n] of a padded output; a problem the rule leaves
+    alone (a full grid, a short k) is the ordinary launch bit for bit."""
+    import ctypes
+    torch, L, ffi = env
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    gate = torch.randn(N, device="cuda", generator=g) if epi == 3 else None
+    ldc = N + 4
+    c0 = torch.randn(M, ldc, device="cuda", generator=g)
+    ws = torch.empty(512 * 128 * 128, device="cuda", dtype=torch.float32)
+    plain = c0.clone()
+    ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), plain.data_ptr(), ldc,
+                            gate.data_ptr() if gate is not None else None, M, N, K, epi, 1, stream(torch)))
+    outs, got = [], ctypes.c_int(0)
+    for i in range(3):
+        ws.fill_(float("nan") if i == 1 else float(i))          # whatever the workspace held
+        c = c0.clone()
+        ffi.check(L.r3g_op_gemm_splitk(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), ldc,
+                                       gate.data_ptr() if gate is not None else None, M, N, K, epi, ws.data_ptr(), ws.numel(),
+                                       ctypes.byref(got), stream(torch)))
+        outs.append(c)
+    assert got.value == slices
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0][:, N:], c0[:, N:])
+    if slices == 1:
+        assert torch.equal(outs[0], plain)
+    else:
+        assert not torch.equal(outs[0], plain)                   # it did take another path ...
+        assert rel_l2(outs[0][:, :N], plain[:, :N]) <= 2e-6      # ... to the same sums
+    lin = a.float() @ w.float().t() + bias
+    want = c0[:, :N] + gate * lin if epi == 3 else lin
+    assert rel_l2(outs[0][:, :N], want) <= 1e-4
+    # the option turns it off
+    try:
+        ffi.check(L.r3g_set_option(b"gemm_splitk128", 0))
+        c = c0.clone()
+        ffi.check(L.r3g_op_gemm_splitk(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), ldc,
+                                       gate.data_ptr() if gate is not None else None, M, N, K, epi, ws.data_ptr(), ws.numel(),
+                                       None, stream(torch)))
+    finally:
+        ffi.check(L.r3g_set_option(b"gemm_splitk128", 1))
+    assert torch.equal(c, plain)
+
+
 def test_gemm_strided_views(env):
     """column slab of a wider weight (ldw > K) and of wider activations / outputs (lda, ldc > width)"""
     torch, L, ffi = env

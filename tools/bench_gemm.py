@@ -41,6 +41,12 @@ SHAPES = {
                (256, 256, 1024, 0), (4442, 768, 1536, 0)],
     # round 5: the two GELU launches of the path (four objects' MLP-in, the geo decoder's c_fc) and a plain one beside them
     "gelu": [(30080, 4096, 1024, 1), (131072, 4096, 1024, 2), (30080, 3072, 1024, 0)],
+    # round 5: the 3 x 3 convolutions of the texture UNets as GEMMs over im2col rows (fp32 outputs), six views and one sample
+    "tex6": [(24576, 320, 2880, 4), (24576, 320, 5760, 4), (24576, 640, 5760, 4), (6144, 640, 5760, 4), (6144, 640, 11520, 4),
+             (6144, 1280, 11520, 4), (1536, 1280, 11520, 4), (1536, 1280, 23040, 4), (384, 1280, 11520, 4), (384, 1280, 23040, 4),
+             (24576, 2560, 320, 0), (6144, 5120, 640, 0), (1536, 10240, 1280, 0), (24576, 320, 1280, 3), (6144, 640, 2560, 3)],
+    "tex1": [(4096, 320, 2880, 4), (4096, 320, 5760, 4), (1024, 640, 5760, 4), (1024, 640, 11520, 4), (256, 1280, 11520, 4),
+             (256, 1280, 23040, 4), (64, 1280, 11520, 4), (64, 1280, 23040, 4), (4096, 2560, 320, 0), (1024, 5120, 640, 0)],
     # ragged edges for the screen
     "edge": [(300, 256, 128, 0), (77, 512, 256, 3), (1371, 1024, 1024, 1), (515, 768, 1024, 3), (4442, 1024, 1536, 4),
              (256, 256, 128, 2), (256, 384, 256, 0), (1000, 448, 384, 1)],
@@ -69,6 +75,8 @@ def main():
     ap.add_argument("--no-lt", action="store_true")
     ap.add_argument("--gelu-pk", default="1", help="comma list of r3g_set_option(\"gelu_pk\") values to time side by side (1: packed "
                                                   "fp16 GELU epilogue, round 5 | 0: the fp32 forms); variants are then keyed 'v/pk'")
+    ap.add_argument("--splitk", action="store_true", help="time r3g_op_gemm_splitk (the texture models' convolution launch) against "
+                                                          "the ordinary launch and hipBLASLt on the fp32-output shapes of the groups")
     a_ = ap.parse_args()
     pks = [int(v) for v in a_.gelu_pk.split(",")]
     variants = [int(v) * 10 + pk for v in a_.variants.split(",") for pk in pks]     # variant * 10 + gelu_pk
@@ -82,6 +90,41 @@ def main():
         ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
                                 gate.data_ptr() if epi in (3, 6) else None, M, N, K, epi, 1, s))
 
+    if a_.splitk:
+        ws = torch.empty(512 * 128 * 128, device="cuda", dtype=torch.float32)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for group in a_.shapes.split(","):
+            for (M, N, K, epi) in SHAPES[group]:
+                if epi not in (3, 4):
+                    continue
+                a, w, bias, gate, c0 = make(M, N, K, epi, M + N + K + epi)
+                c = c0.clone() if epi == 3 else torch.empty(M, N, device="cuda")
+                got = ctypes.c_int(0)
+                fns = {
+                    "plain": lambda: ffi.check(L.r3g_op_gemm(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                                                              gate.data_ptr() if epi == 3 else None, M, N, K, epi, 1, s)),
+                    "splitk": lambda: ffi.check(L.r3g_op_gemm_splitk(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), c.data_ptr(), N,
+                                                                      gate.data_ptr() if epi == 3 else None, M, N, K, epi, ws.data_ptr(),
+                                                                      ws.numel(), ctypes.byref(got), s)),
+                    "lt": lambda: torch.matmul(a, w.t()),
+                }
+                times = {k: [] for k in fns}
+                for rnd in range(a_.rounds + 1):
+                    for k, fn in fns.items():
+                        fn()
+                        ev[0].record()
+                        for _ in range(a_.iters):
+                            fn()
+                        ev[1].record()
+                        torch.cuda.synchronize()
+                        if rnd > 0:
+                            times[k].append(ev[0].elapsed_time(ev[1]) / a_.iters)
+                fl = 2.0 * M * N * K
+                print(json.dumps(dict(op="splitk", M=M, N=N, K=K, epi=epi, slices=got.value,
+                                      us={k: round(1e3 * statistics.median(v), 1) for k, v in times.items()},
+                                      tflops={k: round(fl / statistics.median(v) / 1e9) for k, v in times.items()})), flush=True)
+                del a, w, c
+        return
     for group in a_.shapes.split(","):
         for (M, N, K, epi) in SHAPES[group]:
             a, w, bias, gate, c0 = make(M, N, K, epi, M + N + K + epi)

@@ -5,6 +5,9 @@
 #   micro      MFMA shape microbenchmark, GEMM GELU A/B (bench_gemm), attention generations (bench_attn)
 #   newtests   the GPU tests added this round (RCCL one-rank group, reference script on the GPU, packed GELU, phased attention, fp16 guard)
 #   ab <opts_a> <opts_b> [steps] [warmup]   bench.py A/B/A/B with R3G_OPTIONS=<opts_a> / <opts_b> ("-" = no options)
+#   splitk     split-K of the texture models' convolutions: tests, kernel A/B, texture step A/B
+#   texprof    kernel trace of the texture step
+#   mc / tex / attn   marching-cubes timeline, texture step time, attention generations
 #   suite      the whole -m gpu suite
 #   bench      the driver's invocation of bench.py
 #   evidence <commit> [objects per launch]  kernel trace + PMC passes (tools/profile_evidence.sh), tables -> gpurun_out/r05_*.md
@@ -66,6 +69,26 @@ print("AB ${side}${i} opts='$OPT'", round(d["value"], 4), "obj/s", round(d["ms_p
 PY
         done
     done
+    ;;
+splitk)
+    # split-K of the texture models' convolutions: kernel test, the texture models' tests, A/B of the conv shapes and of the texture step
+    timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "split_k_of_the_convolutions" 2>&1 | tail -5
+    timeout 900 python -m pytest tests/test_unet_gpu.py tests/test_aekl_gpu.py tests/test_unet2p5d_gpu.py -m gpu -q -x 2>&1 | tail -4
+    timeout 300 python tools/bench_gemm.py --splitk --shapes tex6,tex1 --screen 0 --rounds 3 --iters 10 > $O/r05_gemm_splitk.jsonl 2> $O/r05_gemm_splitk.err; tail -2 $O/r05_gemm_splitk.err
+    for v in 0 1; do
+        R3G_OPTIONS="gemm_splitk128=$v" timeout 600 python tests/tex_stage_time.py > $O/r05_texture_stage_time_splitk$v.json 2> $O/r05_texture_stage_time_splitk$v.err
+        grep -o '"times_ms": {[^}]*}' $O/r05_texture_stage_time_splitk$v.json
+    done
+    ;;
+texprof)
+    # where the texture step's time goes at upstream's sizes: kernel trace of tests/tex_stage_time.py, by kernel and by (kernel, grid)
+    R=$(pwd)
+    (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/r05_tex_trace -o t -- python $R/tests/tex_stage_time.py > $R/$O/r05_texture_stage_time_traced.json 2> $R/$O/r05_tex_trace.log)
+    DB=$(ls $O/r05_tex_trace/*/*_results.db $O/r05_tex_trace/*_results.db 2>/dev/null | head -1)
+    python tools/rocprof_summary.py $DB "texture step (tests/tex_stage_time.py: warm-up + whole + delight only + six views only)" > $O/r05_tex_kernel_stats.md
+    python tools/rocprof_summary.py $DB "texture step, by (kernel, grid)" --by-grid > $O/r05_tex_kernel_stats_by_grid.md
+    head -40 $O/r05_tex_kernel_stats.md; head -60 $O/r05_tex_kernel_stats_by_grid.md
+    rm -rf $O/r05_tex_trace
     ;;
 suite)
     timeout 1500 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -40 > $O/r05_gpu_tests.txt
