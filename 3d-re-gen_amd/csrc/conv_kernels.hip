@@ -65,8 +65,11 @@ constexpr int GN_MAX_CPT = 12;   // channels per thread: C <= 3072 (the up block
 // round-4 kernel took 28 us for 64 rows and 43 us for 6 x 4096 rows x 320 channels (31 MB), 10.7 % of the texture step's kernel
 // time (profiles/r05_texture_stage.md).  Every sum keeps a fixed order: rows ascending per (p, channel); per group lane j adds
 // its items j, j + L, ... (item = channel-major, then row lane), then a fixed xor tree over the L lanes.
+// addv (may be null): a vector per sample [sample][add_stride] added to every row of the sample BEFORE the statistics -- the
+// resnet's time_emb_proj(silu(temb)) between conv1 and norm2, which used to be a pass of its own over the rows per sample.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int C, int groups, int rpb,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial, const float* __restrict__ addv,
+                                                         int64_t add_stride) {
     __shared__ float s_sum[256 * GN_MAX_CPT], s_sq[256 * GN_MAX_CPT];     // [row lane][C], P * C <= max(1024, C)
     constexpr int NQ = GN_MAX_CPT / 4;
     const int t = threadIdx.x;
@@ -81,7 +84,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     float4 a[NQ], sq[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) { a[k] = make_float4(0.f, 0.f, 0.f, 0.f); sq[k] = a[k]; }
-    auto add = [](float4& acc, float4& acc2, const float4& v) {
+    if (addv) addv += (int64_t)blockIdx.y * add_stride;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&av](float4& acc, float4& acc2, float4 v) {
+        v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         acc2.x += v.x * v.x; acc2.y += v.y * v.y; acc2.z += v.z * v.z; acc2.w += v.w * v.w;
     };
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             const int q = q0 + k * 256;
             if (q < cq) {
                 const float* col = x + (int64_t)q * 4;
+                if (addv) av = *reinterpret_cast<const float4*>(addv + q * 4);
                 int r = r0 + p;
                 for (; r + 3 * P < r1; r += 4 * P) {
                     float4 v[4];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int rows, int C, int groups,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int do_silu, int rpb,
-                                                       uint16_t* __restrict__ y) {
+                                                       uint16_t* __restrict__ y, const float* __restrict__ addv, int64_t add_stride) {
     __shared__ float s_mean[256], s_rstd[256];
     const int t = threadIdx.x;
     const int cpg = C / groups;
@@ -194,6 +201,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
         const float4 bt = *reinterpret_cast<const float4*>(beta + c);
         const float gw[4] = {gm.x, gm.y, gm.z, gm.w}, bw[4] = {bt.x, bt.y, bt.z, bt.w};
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (addv) av = *reinterpret_cast<const float4*>(addv + (int64_t)blockIdx.y * add_stride + c);
         float mu[4], rs[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             rs[e] = s_rstd[g];
         }
         auto emit = [&](int64_t r, const float4& v) {
-            const float in[4] = {v.x, v.y, v.z, v.w};
+            const float in[4] = {v.x + av.x, v.y + av.y, v.z + av.z, v.w + av.w};
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -374,16 +383,17 @@ int group_norm_blocks(int rows) {
 
 // nb samples of `rows` rows each (contiguous); partial: workspace of nb * (group_norm_blocks(rows) * groups * 2 doubles + groups floats)
 hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
-                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb) {
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb, const float* addv, int64_t add_stride) {
+    if (addv && (add_stride & 3)) return hipErrorInvalidValue;
     if (C % 4 || groups < 1 || groups > 256 || C % groups || C > 256 * GN_MAX_CPT || rows < 1 || nb < 1) return hipErrorInvalidValue;
     const int nblk = group_norm_blocks(rows);
     const int rpb = (rows + nblk - 1) / nblk;
     float* stats = reinterpret_cast<float*>(partial + (int64_t)nb * nblk * groups * 2);
     ProfScope prof_scope_(PC_LAYERNORM, 0.0, s);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, rpb, partial);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, rpb, partial, addv, add_stride);
     hipLaunchKernelGGL(gn_stats_kernel, dim3((groups + 3) / 4, nb), dim3(256), 0, s, (const double*)partial, nblk, groups, rows, C / groups, eps, stats);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nb), dim3(256), 0, s, x, rows, C, groups, (const float*)stats, gamma, beta,
-                       do_silu, rpb, y);
+                       do_silu, rpb, y, addv, add_stride);
     return hipGetLastError();
 }
 

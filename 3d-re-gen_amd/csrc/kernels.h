@@ -226,7 +226,8 @@ hipError_t im2col3x3_launch(const uint16_t* x, int H, int W, int C, int stride, 
 // launches; partial: workspace of nb * (group_norm_blocks(rows) * groups * 2 doubles + groups floats)
 int group_norm_blocks(int rows);
 hipError_t group_norm_launch(const float* x, int rows, int C, int groups, const float* gamma, const float* beta, float eps,
-                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb = 1);
+                             int do_silu, uint16_t* y, double* partial, hipStream_t s, int nb = 1,
+                             const float* addv = nullptr, int64_t add_stride = 0);   // addv [nb][add_stride]: added to every row of its sample first
 // out(bf16)[r][c] = in[r][c] * gelu_erf(in[r][F + c])   (diffusers GEGLU)
 hipError_t geglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t ldo, int rows, int F, hipStream_t s);
 hipError_t vec_add_launch(const float* a, const float* b, float* out, int n, hipStream_t s);

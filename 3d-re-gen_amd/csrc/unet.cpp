@@ -16,6 +16,7 @@
 // extensions of this UNet -- the texture stage keeps reporting its `texture_source` (stage/run.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -149,8 +150,8 @@ static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int st
 
 // GroupNorm (+ SiLU) per sample of f32 rows [nb][hw][C] -> bf16
 static int u_group_norm(Unet& u, const float* x, int hw, int C, const float* g, const float* b, float eps, int silu, uint16_t* y,
-                        hipStream_t s, int nb = 1) {
-    U_TRY(group_norm_launch(x, hw, C, u.c.groups, g, b, eps, silu, y, u.gn_partial, s, nb));     // all samples in one set of launches
+                        hipStream_t s, int nb = 1, const float* addv = nullptr, int64_t add_stride = 0) {
+    U_TRY(group_norm_launch(x, hw, C, u.c.groups, g, b, eps, silu, y, u.gn_partial, s, nb, addv, add_stride));     // all samples in one set of launches
     return R3G_OK;
 }
 
@@ -176,9 +177,15 @@ static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, i
     if (temb) {
         U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
         if (per_sample) {
-            for (int n = 0; n < nb; ++n)
-                U_TRY(gemv_launch(temb + n * temb_stride, 1, u.c.temb_dim, tp.w, tp.K, tp.b, u.vecn + (int64_t)n * u.c.max_channels,
-                                  Cout, 1, 0, s));
+            // every sample's projection: rows of one GEMV launch (8 at a time) where the embeddings lie back to back
+            if (temb_stride == u.c.temb_dim) {
+                for (int n0 = 0; n0 < nb; n0 += 8)
+                    U_TRY(gemv_launch(temb + n0 * temb_stride, std::min(8, nb - n0), u.c.temb_dim, tp.w, tp.K, tp.b,
+                                      u.vecn + (int64_t)n0 * Cout, Cout, 1, 0, s));
+            } else {
+                for (int n = 0; n < nb; ++n)
+                    U_TRY(gemv_launch(temb + n * temb_stride, 1, u.c.temb_dim, tp.w, tp.K, tp.b, u.vecn + (int64_t)n * Cout, Cout, 1, 0, s));
+            }
         } else {
             float* tb = u.vec;
             float* sum = u.vec + u.c.max_channels;
@@ -189,10 +196,8 @@ static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, i
     }
     U_RC(u_group_norm(u, x, hw, Cin, g1, b1, u.c.resnet_eps, 1, u.xn, s, nb));
     U_RC(u_conv3x3(u, u.xn, H, W, Cin, 1, c1, cb, u.t1, EPI_F32, s, 1, nb));
-    if (per_sample)
-        for (int n = 0; n < nb; ++n)
-            U_TRY(add_rows_launch(u.t1 + (int64_t)n * hw * Cout, Cout, u.vecn + (int64_t)n * u.c.max_channels, 0, hw, Cout, s));
-    U_RC(u_group_norm(u, u.t1, hw, Cout, g2, b2, u.c.resnet_eps, 1, u.xn, s, nb));
+    // per sample: norm2 reads conv1's rows + the sample's projection (u.vecn [nb][Cout]); the sum is not stored
+    U_RC(u_group_norm(u, u.t1, hw, Cout, g2, b2, u.c.resnet_eps, 1, u.xn, s, nb, per_sample ? u.vecn : nullptr, Cout));
     // the residual: x itself, or conv_shortcut (1x1) of x, lands in `out` first; conv2's epilogue adds onto it
     if (Cin != Cout || u.w.count(pre + ".conv_shortcut.weight")) {
         ULin sc;
@@ -239,11 +244,13 @@ static GemmArgs u_qkv_args(const uint16_t* A, int64_t lda, const ULin& l, int M,
 }
 
 // h += gate * (att . W^T + b)   (gate: a constant per-column vector, or null for 1)
-static int u_gemm_resid(const uint16_t* A, int64_t lda, const ULin& l, float* C, int64_t ldc, int M, const float* gate, hipStream_t s) {
+static int u_gemm_resid(const uint16_t* A, int64_t lda, const ULin& l, float* C, int64_t ldc, int M, const float* gate, hipStream_t s,
+                        float* split_ws = nullptr) {
     GemmArgs p{};
     p.A = A; p.lda = lda; p.W = l.w; p.ldw = l.K; p.bias = l.b; p.C = C; p.ldc = ldc;
     p.M = M; p.N = l.N; p.K = l.K; p.epi = EPI_RESID_F32;
     p.gate = gate; p.strideGate = 0;
+    p.split_ws = split_ws; p.split_ws_elems = split_ws ? kSplitWsElems : 0;   // the feed-forward's way back (K = 4 C) at the coarse levels
     hipError_t e = gemm_launch(p, 1, s);
     if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet residual)");
     return R3G_OK;
@@ -355,7 +362,7 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
     U_RC(u_layernorm(u.h, u.xn, rows, C, w3, b3, 1e-5f, s));
     U_RC(u_gemm(u.xn, C, f0, f0.b, u.ff, 8 * (int64_t)C, rows, EPI_BF16, s));
     U_TRY(geglu_launch(u.ff, 8 * (int64_t)C, u.ff2, 4 * (int64_t)C, rows, 4 * C, s));
-    U_RC(u_gemm_resid(u.ff2, 4 * (int64_t)C, f2, u.h, C, rows, nullptr, s));
+    U_RC(u_gemm_resid(u.ff2, 4 * (int64_t)C, f2, u.h, C, rows, nullptr, s, u.splitws));
     // proj_out + the block's input
     U_TRY(f32_to_bf16_launch(u.h, u.xn, (int64_t)rows * C, s));
     return u_gemm_resid(u.xn, C, pout, x, C, rows, nullptr, s);
