@@ -78,3 +78,4 @@ def test_reference_stage_script_unmodified_on_the_gpu(tmp_path, route):
         got = validate_glb(data)
         assert got["image"] is not None and "TEXCOORD_0" in got["attributes"]
         assert "Saved %s" % stem in r.stdout
+    print("\n---- the reference script's own output (route %s), last lines ----\n%s" % (route, "\n".join(r.stdout.strip().splitlines()[-22:])))   # shown under -s: the log in profiles/

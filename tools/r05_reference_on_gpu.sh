@@ -10,5 +10,8 @@ mkdir -p $DST/src/2d_to_3d_models $DST/src/utils
 cp $REF/src/2d_to_3d_models/run.py $DST/src/2d_to_3d_models/run.py
 cp $REF/src/utils/global_utils.py $DST/src/utils/global_utils.py
 trap 'rm -rf /root/repo/oracle/_ref/reference_src' EXIT
-/usr/local/graft/bin/gpurun --timeout ${1:-600} -- 'mkdir -p gpurun_out; timeout 500 python -m pytest tests/test_reference_script_gpu.py -m gpu -q -rs 2>&1 | tail -30 > gpurun_out/r05_reference_script_gpu.txt; cat gpurun_out/r05_reference_script_gpu.txt'
-cp gpurun_out/r05_reference_script_gpu.txt profiles/r05_reference_script_gpu.txt
+/usr/local/graft/bin/gpurun --timeout ${1:-600} -- 'mkdir -p gpurun_out; timeout 500 python -m pytest tests/test_reference_script_gpu.py -m gpu -v -s -rs 2>&1 | grep -v amdgpu.ids | tail -70 > gpurun_out/r05_reference_script_gpu.txt; cat gpurun_out/r05_reference_script_gpu.txt'
+{ echo "# round 5: the reference's own stage script (src/2d_to_3d_models/run.py, unmodified) on one MI355X through libr3g.so -- INTEGRATION.md route 1,"
+  echo "# both of its routes (sequential :194-213, multiprocessing pool :176-193); tools/r05_reference_on_gpu.sh, commit $(git rev-parse --short HEAD), mini-sized synthetic snapshot"
+  echo "# (the pool's workers are spawned processes: the parent, whose maps the last line of that route reports, never loads the library)"
+  cat gpurun_out/r05_reference_script_gpu.txt; } > profiles/r05_reference_script_gpu.txt
