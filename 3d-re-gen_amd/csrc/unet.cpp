@@ -67,6 +67,7 @@ struct Unet {
     std::unordered_map<std::string, Cond> cond;
     int nb = 1;                            // samples in the running forward
     int mv_flags = 0;                      // 1: write the condition store | 2: read it (reference attention)
+    int groups = 1;                        // 2 (flag 4): the samples are a classifier-free-guidance PAIR of nb / 2 views each
     float mva_scale = 1.0f, ref_scale = 1.0f;
 };
 constexpr int kMaxViews = 16;
@@ -269,7 +270,12 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
                             hipStream_t s, int nb = 1) {
     U_RC(u_check_shape(u, H, W, C, "r3g_unet_transformer", nb));
     if (tokens < 1 || tokens > u.c.ctx_tokens) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: %d context tokens (max %d)", tokens, u.c.ctx_tokens);
-    const int hw = H * W, rows = nb * hw, heads = C / 64, Lp = (int)rup(hw, 128), Lkp = (int)rup(tokens, 64), Lall = (int)rup(rows, 128);
+    const int hw = H * W, rows = nb * hw, heads = C / 64, Lp = (int)rup(hw, 128), Lkp = (int)rup(tokens, 64);
+    // sample groups (round 5): G = 2 is the guidance pair -- group 0 the conditional evaluation (context rows [0, tokens), reference
+    // attention under flag 2), group 1 the unconditional one (context rows [tokens, 2 tokens), no reference attention); the
+    // multiview attention's sequence is a GROUP's views.  One launch set instead of two; G = 1 is exactly rounds 3-4.
+    const int G = (nb > 1 && u.groups == 2 && nb % 2 == 0) ? 2 : 1;
+    const int rows_g = rows / G, Lall = (int)rup(rows_g, 128);
     const std::string blk = pre + ".transformer_blocks.0";
     const float *gw, *gb, *w1, *b1, *w2, *b2, *w3, *b3;
     U_RC(u_vec(u, pre + ".norm.weight", C, &gw));
@@ -293,7 +299,7 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
     const bool has_mv = nb > 1 && u.w.count(blk + ".attn_multiview.to_qkv.weight");
     const auto cond_it = u.w.find("cond:" + pre);
     const bool has_ref = (u.mv_flags & 2) && cond_it != u.w.end() && u.w.count(blk + ".attn_refview.to_q.weight");
-    if (nb * (int64_t)Lp > Lall + 128 * kMaxViews) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: padded query rows exceed the arena");
+    if (nb * (int64_t)Lp > (int64_t)G * Lall + 128 * kMaxViews) return fail(R3G_ERR_INVALID, "r3g_unet_transformer: padded query rows exceed the arena");
     // norm (GroupNorm, no activation) -> proj_in -> hidden state h
     U_RC(u_group_norm(u, x, hw, C, gw, gb, 1e-6f, 0, u.xn, s, nb));
     U_RC(u_gemm(u.xn, C, pin, pin.b, u.h, C, rows, EPI_F32, s));
@@ -327,36 +333,40 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
         U_RC(u_lin(u, blk + ".attn_refview.to_q", false, C, C, &rq));
         U_RC(u_lin(u, blk + ".attn_refview.to_kv", false, 2 * C, C, &rkv));
         U_RC(u_lin(u, blk + ".attn_refview.to_out.0", true, C, C, &ro));
-        const GemmArgs pq = u_qkv_args(u.xn, C, rq, rows, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
+        // (the guidance pair: only group 0's rows -- the first rows_g -- take the reference attention)
+        const GemmArgs pq = u_qkv_args(u.xn, C, rq, rows_g, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
         hipError_t e = gemm_launch(pq, 1, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet refview q)");
         const GemmArgs pk = u_qkv_args((const uint16_t*)ct.p, C, rkv, rt, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lrp);
         e = gemm_launch(pk, 1, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet refview kv)");
-        U_RC(u_attention(u, heads, rows, Lall, rt, Lrp, u.ctxK, u.ctxVt, C, s));
-        U_RC(u_gemm_resid(u.att, C, ro, u.h, C, rows, u.ref_scale != 1.0f ? u.gate + u.c.max_channels : nullptr, s));
+        U_RC(u_attention(u, heads, rows_g, Lall, rt, Lrp, u.ctxK, u.ctxVt, C, s));
+        U_RC(u_gemm_resid(u.att, C, ro, u.h, C, rows_g, u.ref_scale != 1.0f ? u.gate + u.c.max_channels : nullptr, s));
     }
     if (has_mv) {                  // multiview attention: the tokens of all views form one sequence
         ULin mq, mo;
         U_RC(u_lin(u, blk + ".attn_multiview.to_qkv", false, 3 * C, C, &mq));
         U_RC(u_lin(u, blk + ".attn_multiview.to_out.0", true, C, C, &mo));
-        const GemmArgs p = u_qkv_args(u.xn, C, mq, rows, heads, QKV_KHD, u.Q, u.K, u.Vt, Lall, Lall);
-        hipError_t e = gemm_launch(p, 1, s);
+        GemmArgs p = u_qkv_args(u.xn, C, mq, rows_g, heads, QKV_KHD, u.Q, u.K, u.Vt, Lall, Lall);
+        p.strideA = (int64_t)rows_g * C;           // a group per GEMM batch = per attention batch
+        hipError_t e = gemm_launch(p, G, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet multiview qkv)");
-        U_RC(u_attention(u, heads, rows, Lall, rows, Lall, u.K, u.Vt, C, s));
+        U_RC(u_attention(u, heads, rows_g, Lall, rows_g, Lall, u.K, u.Vt, C, s, G));
         U_RC(u_gemm_resid(u.att, C, mo, u.h, C, rows, u.mva_scale != 1.0f ? u.gate : nullptr, s));
     }
-    // cross-attention over the context tokens (the same context for every sample: all rows are one batch of queries)
+    // cross-attention over the context tokens (one context per group: a group's rows are one batch of queries over its context)
     U_RC(u_layernorm(u.h, u.xn, rows, C, w2, b2, 1e-5f, s));
     {
-        const GemmArgs pq = u_qkv_args(u.xn, C, q2, rows, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
-        hipError_t e = gemm_launch(pq, 1, s);
+        GemmArgs pq = u_qkv_args(u.xn, C, q2, rows_g, heads, QKV_Q_ONLY, u.Q, nullptr, nullptr, Lall, 0);
+        pq.strideA = (int64_t)rows_g * C;
+        hipError_t e = gemm_launch(pq, G, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet q)");
-        const GemmArgs pk = u_qkv_args(ctx, u.c.ctx_dim, kv2, tokens, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lkp);
-        e = gemm_launch(pk, 1, s);
+        GemmArgs pk = u_qkv_args(ctx, u.c.ctx_dim, kv2, tokens, heads, QKV_HEAD_KV, nullptr, u.ctxK, u.ctxVt, 0, Lkp);
+        pk.strideA = (int64_t)tokens * u.c.ctx_dim;
+        e = gemm_launch(pk, G, s);
         if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet kv)");
     }
-    U_RC(u_attention(u, heads, rows, Lall, tokens, Lkp, u.ctxK, u.ctxVt, C, s));
+    U_RC(u_attention(u, heads, rows_g, Lall, tokens, Lkp, u.ctxK, u.ctxVt, C, s, G));
     U_RC(u_gemm_resid(u.att, C, o2, u.h, C, rows, nullptr, s));
     // GEGLU feed-forward
     U_RC(u_layernorm(u.h, u.xn, rows, C, w3, b3, 1e-5f, s));
@@ -698,7 +708,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     const size_t o_h = carve(hw * C * 4), o_t1 = carve(hw * C * 4), o_xn = carve(hw * C * 2), o_col = carve(hw * 9 * C * 2),
                  o_q = carve(heads * hwp * 64 * 2), o_k = carve(heads * hwp * 64 * 2), o_v = carve(heads * hwp * 64 * 2),
                  o_att = carve(hw * C * 2), o_ff = carve(hw * 8 * C * 2), o_ff2 = carve(hw * 4 * C * 2),
-                 o_ck = carve(heads * ckp * 64 * 2), o_cv = carve(heads * ckp * 64 * 2), o_vec = carve(4 * C * 4),
+                 o_ck = carve(2 * heads * ckp * 64 * 2), o_cv = carve(2 * heads * ckp * 64 * 2),   /* two contexts: the guidance pair */ o_vec = carve(4 * C * 4),
                  o_gn = carve((int64_t)kMaxViews * (256LL * 256 * 2 * 8 + 256 * 2 * 4)), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
                  o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4), o_vecn = carve((int64_t)kMaxViews * C * 4),
                  o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4), o_split = carve(kSplitWsElems * 4);
@@ -804,8 +814,10 @@ int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width,
 // the constant gate vectors of the 2.5D attention branches (mva_scale | ref_scale) and the mode of the pass
 static int mv_begin(Unet& u, int n_views, int flags, float mva_scale, float ref_scale, hipStream_t s, const char* fn) {
     if (n_views < 1 || n_views > kMaxViews) return fail(R3G_ERR_INVALID, "%s: n_views must be in [1, %d]", fn, kMaxViews);
-    if (flags & ~3) return fail(R3G_ERR_INVALID, "%s: flags is a combination of 1 (write the reference states) and 2 (read them)", fn);
-    u.mv_flags = flags; u.mva_scale = mva_scale; u.ref_scale = ref_scale;
+    if (flags & ~7) return fail(R3G_ERR_INVALID, "%s: flags is a combination of 1 (write the reference states), 2 (read them) and 4 (guidance pair)", fn);
+    if ((flags & 4) && ((n_views & 1) || (flags & 1)))
+        return fail(R3G_ERR_INVALID, "%s: flag 4 (the samples are a guidance pair) needs an even n_views and excludes flag 1", fn);
+    u.mv_flags = flags & 3; u.groups = (flags & 4) ? 2 : 1; u.mva_scale = mva_scale; u.ref_scale = ref_scale;
     uint32_t bits[2];
     std::memcpy(&bits[0], &mva_scale, 4);
     std::memcpy(&bits[1], &ref_scale, 4);
@@ -823,7 +835,7 @@ int r3g_unet_forward_mv(r3g_ctx* ctx, const float* d_sample, int height, int wid
     int rc = mv_begin(*u, n_views, flags, mva_scale, ref_scale, s, "r3g_unet_forward_mv");
     if (rc) return rc;
     rc = unet_forward(*u, d_sample, height, width, timestep, d_ctx, tokens, d_out, s, n_views, class_labels);
-    u->mv_flags = 0;
+    u->mv_flags = 0; u->groups = 1;
     return rc;
 }
 
@@ -835,7 +847,7 @@ int r3g_unet_transformer_mv(r3g_ctx* ctx, const char* prefix, float* d_x, int he
     int rc = mv_begin(*u, n_views, flags, mva_scale, ref_scale, s, "r3g_unet_transformer_mv");
     if (rc) return rc;
     rc = unet_transformer(*u, prefix, d_x, height, width, channels, d_ctx, tokens, s, n_views);
-    u->mv_flags = 0;
+    u->mv_flags = 0; u->groups = 1;
     return rc;
 }
 

@@ -25,8 +25,10 @@ class MultiviewUNet:
         self.n_levels, self.layers = len(ch), c["layers_per_block"]
         common = dict(max_channels=2 * max(ch), temb_dim=c["temb_dim"], ctx_dim=c["cross_attention_dim"], groups=c["groups"],
                       device=device, block_out_channels=ch, layers_per_block=c["layers_per_block"], out_channels=4)
-        self.gen = _unet.UnetBlocks(gen_sd, max_hw=n_views_max * latent_hw, ctx_tokens=max(c["ctx_tokens"], n_ref_max * latent_hw),
-                                    in_channels=12, **common)
+        # the generator's arena holds the TWO evaluations of a guidance step side by side (2 x n_views_max samples, <= 16)
+        self.pair_capacity = 2 * n_views_max <= 16
+        self.gen = _unet.UnetBlocks(gen_sd, max_hw=(2 if self.pair_capacity else 1) * n_views_max * latent_hw,
+                                    ctx_tokens=max(c["ctx_tokens"], n_ref_max * latent_hw), in_channels=12, **common)
         self.ref = _unet.UnetBlocks(ref_sd, max_hw=n_ref_max * latent_hw, ctx_tokens=c["ctx_tokens"], in_channels=4, **common)
         self.text_gen = extra["learned_text_clip_gen"].detach().reshape(1, -1, c["cross_attention_dim"])
         self.text_ref = extra["learned_text_clip_ref"].detach().reshape(1, -1, c["cross_attention_dim"])
@@ -62,7 +64,7 @@ class MultiviewPipeline:
     unconditional branch: zero reference latents with ref_scale 0), combined as uncond + g (cond - uncond); the views are decoded
     one by one.  Latents, conditioning latents and noise stay in HBM as rows for the whole loop."""
 
-    def __init__(self, unet, vae, scaling_factor=0.18215, prediction_type="epsilon", uncond_context="zeros"):
+    def __init__(self, unet, vae, scaling_factor=0.18215, prediction_type="epsilon", uncond_context="zeros", paired_guidance=True):
         """uncond_context: the text context of the UNCONDITIONAL branch of classifier-free guidance.  "zeros" (default):
         [UPSTREAM-RECALLED] HunyuanPaintPipeline sets negative_prompt_embeds = zeros_like(prompt_embeds) -- the branch runs without
         the reference attention AND on an all-zero context; "learned": the learned embedding in both branches (rounds 2-3).
@@ -71,6 +73,9 @@ class MultiviewPipeline:
         if uncond_context not in ("zeros", "learned"):
             raise ValueError("uncond_context must be 'zeros' or 'learned'")
         self.uncond_context = uncond_context
+        # paired_guidance: both evaluations of a guided step as ONE launch set of 2 n samples (round 5; r3g_unet_forward_mv flag 4)
+        # where the generator's arena has the room; False: two launch sets of n samples (rounds 3-4)
+        self.paired_guidance = bool(paired_guidance)
         self.unet, self.vae = unet, vae
         self.scaling_factor = float(scaling_factor)
         self.scheduler = _sched.EulerAncestralDiscrete(prediction_type=prediction_type, timestep_spacing="trailing")
@@ -111,16 +116,27 @@ class MultiviewPipeline:
         sch = self.scheduler.set_timesteps(steps)
         x = _unet.to_rows(noise["latents"].to(dev)) * sch.init_noise_sigma
         step_noise = [_unet.to_rows(e.to(dev)) for e in noise["steps"]]
-        inp = torch.empty((n * h * w, 3 * zc), dtype=torch.float32, device=dev)
-        eps_c = torch.empty((n * h * w, zc), dtype=torch.float32, device=dev)
-        eps_u = torch.empty_like(eps_c)
+        guided = guidance_scale > 1.0
+        paired = guided and self.paired_guidance and getattr(self.unet, "pair_capacity", False) and 2 * n <= 16
+        rows1 = n * h * w
+        inp2 = torch.empty(((2 if paired else 1) * rows1, 3 * zc), dtype=torch.float32, device=dev)
+        inp = inp2[:rows1]
+        eps2 = torch.empty((2 * rows1, zc), dtype=torch.float32, device=dev)
+        eps_c, eps_u = eps2[:rows1], eps2[rows1:]
+        ctx2 = torch.cat([ctx, ctx_u], dim=0).contiguous()
+        labels2 = None if labels is None else list(labels) + list(labels)
         gen = self.unet.gen
         for i in range(steps):
             t = float(sch.timesteps[i])
             sch.model_input(x, cond_rows, i, out=inp)
-            gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=2, out=eps_c)
-            if guidance_scale > 1.0:
-                gen.forward_mv_rows(inp, n, h, w, t, ctx_u, class_labels=labels, flags=0, out=eps_u)
+            if paired:
+                inp2[rows1:].copy_(inp)
+                gen.forward_mv_rows(inp2, 2 * n, h, w, t, ctx2, class_labels=labels2, flags=2 | 4, out=eps2)
+            else:
+                gen.forward_mv_rows(inp, n, h, w, t, ctx, class_labels=labels, flags=2, out=eps_c)
+                if guided:
+                    gen.forward_mv_rows(inp, n, h, w, t, ctx_u, class_labels=labels, flags=0, out=eps_u)
+            if guided:
                 sch.cfg_combine(eps_u, eps_c, guidance_scale, out=eps_c)
             sch.step(x, eps_c, step_noise[i], i)
         if output == "latent":

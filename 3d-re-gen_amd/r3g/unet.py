@@ -238,13 +238,16 @@ class UnetBlocks(_OwnsContext):
         return from_rows(out, h, w, n)
 
     def forward_mv_rows(self, rows, n, h, w, timestep, ctx_rows, class_labels=None, flags=0, mva_scale=1.0, ref_scale=1.0, out=None):
-        """the same on rows already in HBM: rows f32 [n*h*w][in_channels], ctx_rows bf16 [tokens][ctx_dim]"""
+        """the same on rows already in HBM: rows f32 [n*h*w][in_channels], ctx_rows bf16 [tokens][ctx_dim].  flags & 4: the n samples
+        are a classifier-free-guidance pair (n / 2 conditional, then n / 2 unconditional views) and ctx_rows holds both contexts,
+        [2 tokens][ctx_dim] (include/r3g.h: r3g_unet_forward_mv)"""
         if out is None:
             out = torch.empty((n * h * w, self.out_channels), dtype=torch.float32, device=self.device)
         lab = None if class_labels is None else (ctypes.c_int32 * n)(*[int(v) for v in class_labels])
+        tokens = ctx_rows.shape[0] // 2 if (int(flags) & 4) else ctx_rows.shape[0]
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_unet_forward_mv(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), ctx_rows.data_ptr(),
-                                                ctx_rows.shape[0], n, lab, int(flags), ctypes.c_float(float(mva_scale)),
+                                                tokens, n, lab, int(flags), ctypes.c_float(float(mva_scale)),
                                                 ctypes.c_float(float(ref_scale)), out.data_ptr(), self._s()))
         return out
 

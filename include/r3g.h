@@ -295,7 +295,12 @@ int r3g_unet_forward(r3g_ctx* ctx, const float* d_sample, int height, int width,
  * "cond:<transformer prefix>" = the reference pass's kept states (bf16 [reference tokens][C], from r3g_unet_condition of the
  * context that ran the reference pass).  Blocks whose 2.5D weights are not registered run as the plain block.
  * flags: 1 = keep norm1's output of every transformer ("w" mode, the reference pass), 2 = run attn_refview where its weights
- * and "cond:" tensor exist ("r" mode).  class_labels: host array [n_views] or NULL. */
+ * and "cond:" tensor exist ("r" mode), 4 = the n_views samples are the two evaluations of one classifier-free-guidance step in
+ * ONE launch set (round 5; n_views even, not with flag 1): samples [0, n_views/2) are the conditional evaluation -- context rows
+ * [0, tokens) of d_ctx, attn_refview under flag 2 --, samples [n_views/2, n_views) the unconditional one -- context rows
+ * [tokens, 2 tokens) of d_ctx (bf16 [2 tokens][ctx_dim]), no attn_refview --, and attn_multiview's sequence is one HALF's
+ * views; every sample's result equals its two-call result up to the order of fp32 additions in the split-K convolutions.
+ * max_hw must then hold n_views*height*width rows.  class_labels: host array [n_views] or NULL. */
 int r3g_unet_forward_mv(r3g_ctx* ctx, const float* d_sample, int height, int width, float timestep, const uint16_t* d_ctx, int tokens,
                         int n_views, const int32_t* class_labels, int flags, float mva_scale, float ref_scale, float* d_out,
                         void* stream);

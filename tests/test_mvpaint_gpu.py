@@ -83,6 +83,22 @@ def test_sampling_loop_small(pair, n, size, steps, g):
     assert ez < 5e-2 and ei < 5e-2, (ez, ei)
 
 
+def test_paired_guidance_is_the_two_launch_sets(pair):
+    """the guided loop with both evaluations of a step in ONE launch set (the default since round 5) against the same loop with two
+    launch sets per step (rounds 3-4): the same latents after 8 steps up to the fp32 addition order of the split-K convolutions"""
+    import torch
+    from r3g.multiview import MultiviewPipeline
+    ref, nm, ps, noise = _inputs(6, 1, 64, 8, 77)
+    cams = list(range(6))
+    assert pair.pipe.paired_guidance and pair.gpu_unet.pair_capacity
+    one = pair.pipe(ref, nm, ps, cams, [0], num_inference_steps=8, guidance_scale=2.0, noise=noise, output="latent").cpu()
+    two_sets = MultiviewPipeline(pair.gpu_unet, pair.gpu_vae, paired_guidance=False)
+    two = two_sets(ref, nm, ps, cams, [0], num_inference_steps=8, guidance_scale=2.0, noise=noise, output="latent").cpu()
+    e = rel_l2(one, two)
+    report("mvpaint.loop 6 views 64x64, 8 steps: one launch set per guided step vs two", e, 1e-4)
+    assert e <= 1e-4
+
+
 def test_upstream_flow_through_the_paint_pipeline(pair):
     """delight -> unwrap -> normal / position maps of six views -> multiview diffusion -> bake -> inpaint, every model on the HIP
     blocks (random weights: the colours mean nothing, the plumbing is what is checked)"""

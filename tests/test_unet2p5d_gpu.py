@@ -84,6 +84,41 @@ def test_whole_evaluation_small(small, n_views, n_ref, hw, scales):
     assert rel_l2(got, indep) > 5 * e                          # the cross-view / reference branches are not a rounding effect
 
 
+@pytest.mark.parametrize("n_views,hw", [(6, 16), (3, 8)])
+def test_guidance_pair_in_one_launch_set_equals_the_two_calls(small, n_views, hw):
+    """r3g_unet_forward_mv flag 4 (round 5): the conditional evaluation (learned context, reference attention) and the unconditional one
+    (zero context, no reference attention) of a guided step as ONE launch set of 2 n samples -- every sample's prediction is the
+    two-call one (the same kernels per row; only the split-K convolutions may add their slices in another order)"""
+    import torch
+    from r3g import unet as RU
+    gpu = small.gpu
+    g = torch.Generator().manual_seed(50 + n_views)
+    ref = torch.randn(1, 4, hw, hw, generator=g)
+    x, nm, ps = (torch.randn(n_views, 4, hw, hw, generator=g) for _ in range(3))
+    gpu.reference_pass(ref, [0])
+    dev = gpu.gen.device
+    rows = RU.to_rows(torch.cat([x, nm, ps], dim=1).to(dev))
+    ctx = gpu.text_gen[0].to(dev, torch.bfloat16).contiguous()
+    ctx_u = torch.zeros_like(ctx)
+    labels = [v + gpu.max_num_ref_image for v in range(n_views)]
+    kw = dict(mva_scale=0.8, ref_scale=1.3)
+    cond = gpu.gen.forward_mv_rows(rows, n_views, hw, hw, 481.0, ctx, class_labels=labels, flags=2, **kw).clone()
+    unc = gpu.gen.forward_mv_rows(rows, n_views, hw, hw, 481.0, ctx_u, class_labels=labels, flags=0, **kw).clone()
+    both = gpu.gen.forward_mv_rows(torch.cat([rows, rows], dim=0).contiguous(), 2 * n_views, hw, hw, 481.0,
+                                   torch.cat([ctx, ctx_u], dim=0).contiguous(), class_labels=labels + labels, flags=2 | 4, **kw)
+    n = rows.shape[0]
+    assert torch.isfinite(both).all()
+    ec, eu = rel_l2(both[:n].cpu(), cond.cpu()), rel_l2(both[n:].cpu(), unc.cpu())
+    report("unet2p5d.guidance pair in one launch set vs two calls, %d views: conditional half" % n_views, ec, 1e-5)
+    report("unet2p5d.guidance pair in one launch set vs two calls, %d views: unconditional half" % n_views, eu, 1e-5)
+    assert ec <= 1e-5 and eu <= 1e-5
+    assert rel_l2(cond.cpu(), unc.cpu()) > 1e-2                  # the two evaluations do differ: the halves were not mixed up
+    # the pair again gives the same bits (the context's group stride, the padded query rows between the groups)
+    again = gpu.gen.forward_mv_rows(torch.cat([rows, rows], dim=0).contiguous(), 2 * n_views, hw, hw, 481.0,
+                                    torch.cat([ctx, ctx_u], dim=0).contiguous(), class_labels=labels + labels, flags=2 | 4, **kw)
+    assert torch.equal(again, both)
+
+
 def test_single_view_without_reference_is_the_plain_forward(small):
     import torch
     m, gpu = small.oracle, small.gpu
@@ -109,7 +144,7 @@ def test_errors(small):
     with pytest.raises(ffi.R3GError):
         gpu.gen.forward_mv(torch.zeros(3, 12, 8, 8), 1.0, gpu.text_gen, flags=4)
     with pytest.raises(ffi.R3GError):
-        gpu.gen.forward_mv(torch.zeros(7, 12, 16, 16), 1.0, gpu.text_gen)                              # 7 x 256 rows > the arena's 6 x 256
+        gpu.gen.forward_mv(torch.zeros(13, 12, 16, 16), 1.0, gpu.text_gen)                             # 13 x 256 rows > the arena's 2 x 6 x 256 (a guidance pair of 6 views)
     with pytest.raises(ffi.R3GError):
         gpu.gen.condition("down_blocks.0.attentions.0")                                                 # the generator never ran with flag 1
 
