@@ -87,8 +87,9 @@ int r3g_mc_emit(r3g_ctx* ctx, float* d_verts, int32_t* d_faces, const double* xf
  *   reduce_faces     : no-op when *n_faces <= max_faces; otherwise quadric-error-metric edge collapse (the algorithm
  *                      class of upstream's MeshLab filter) in rounds of independent collapses: every vertex picks its
  *                      cheapest valid edge (optimal placement; link condition, no face turning by more than ~78
- *                      degrees, no slivers, boundary vertices stay on the boundary), mutually chosen edges whose
- *                      neighbourhoods do not overlap collapse simultaneously, the last round is cut at the key that
+ *                      degrees, no slivers, boundary vertices stay on the boundary) and PROPOSES it; per round a maximal
+ *                      set of proposals with pairwise disjoint closed neighbourhoods is selected (three Luby iterations on
+ *                      the fixed (key, proposer) order, round 4) and collapses simultaneously, the last round is cut at the key that
  *                      meets the budget (result within 1 % below max_faces).  Closed surfaces stay closed manifolds
  *                      of the same genus.  Equivalence with MeshLab is geometric, not index-wise.
  *   cluster_faces    : vertex clustering on a uniform grid over the bounding box (first resolution
