@@ -732,6 +732,120 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs pa, GemmArgs pb)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM 3 x 3 convolution (round 5): gemm_kernel<EPI, true, 8, 0> (128 x 128 tile, 8 waves of 32 x 64, two LDS stages) with
+// the A operand gathered straight from the activation rows -- the im2col matrix (18 bytes written and read per input element,
+// 7-8 % of the texture step's kernel time at HBM speed, profiles/r05_texture_stage.md) is never materialised.  A lane stages the
+// same tile rows in every k-step, so its output pixel (sample, oy, ox) is decomposed ONCE; a k-step of 64 lies inside one tap
+// (Cin % 64 == 0), so per k-step the lane adds the tap's (dy, dx), tests the image border and points the LDS-DMA at the pixel's
+// channels or at 128 bytes of zeros.  Same fragment layout, k order and MFMA shape as the GEMM on the im2col matrix: the results
+// are bit-identical to it.  Split-K: slice `batch` covers k in [batch K, (batch + 1) K) of the 9 Cin columns (W advances by strideW).
+template <int EPI>
+__global__ __launch_bounds__(512) void conv_gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8, WN = 2, BM = 128, BN = 128, MI = 2, WROWS = 32;
+    constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE_BYTES = TILE_A + TILE_W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int rg = p.raster_group < 0 ? (tiles_n >= 16 ? 4 : 0) : p.raster_group;
+    const int GN = rg > 0 ? rg : tiles_n;
+    const int rows_all = tiles_m * p.batch;
+    const int per_group = rows_all * GN;
+    const int group = wg / per_group;
+    const int within = wg - group * per_group;
+    const int gn_cur = (tiles_n - group * GN) < GN ? (tiles_n - group * GN) : GN;
+    const int rowi = within / gn_cur;
+    const int tn = group * GN + (within - rowi * gn_cur);
+    const int batch = rowi / tiles_m;
+    const int tm = rowi - batch * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* W = p.W + (int64_t)batch * p.strideW;
+    const int wr = wid / WN, wc = wid % WN;
+    const ConvA& cv = p.conv;
+
+    // the two 8-row pieces this wave stages per k-step: the lane's output pixel, decomposed once
+    int iy0[2], ix0[2], pix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wid * 2 + i) * 8 + (lane >> 3);
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const int hw_o = cv.Ho * cv.Wo;
+        const int n = m / hw_o, rem = m - n * hw_o;
+        const int oy = rem / cv.Wo, ox = rem - oy * cv.Wo;
+        iy0[i] = oy * cv.stride - cv.pad;
+        ix0[i] = ox * cv.stride - cv.pad;
+        pix[i] = n * cv.H * cv.W;
+    }
+    const int kbase = batch * p.K;
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int t, int slot) {
+        char* base = smem + slot * STAGE_BYTES;
+        const int k0 = kbase + t * BK;                 // wave-uniform: the tap and the channel offset of this k-step
+        const int tap = k0 / cv.Cin, c0 = k0 - tap * cv.Cin;
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int row = piece * 8 + (lane >> 3);
+            const int kc = (lane & 7) ^ ((row >> 1) & 7);
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool inside = (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
+            const uint16_t* g = inside ? cv.x + ((int64_t)(pix[i] + iy * cv.W + ix) * cv.Cin + c0 + kc * 8) : cv.zero + kc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, 0, 0);
+        }
+        stage_tile<true, NW, BN>(W, p.ldw, n0, p.N, t * BK, base + TILE_A, wid, lane, tid);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int offA[MI], offB[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rowA = wr * WROWS + i * 16 + (lane & 15);
+        offA[i] = rowA * 128 + ((((lane >> 4)) ^ ((rowA >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowB = wc * 64 + i * 16 + (lane & 15);
+        offB[i] = rowB * 128 + ((((lane >> 4)) ^ ((rowB >> 1) & 7)) << 4);
+    }
+    for (int t = 0; t < nk; ++t) {
+        const int slot = t & 1;
+        const char* cur = smem + slot * STAGE_BYTES;
+        if (t + 1 < nk) stage(t + 1, slot ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI], b[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + (offA[i] ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(cur + TILE_A + (offB[i] ^ (kk << 6)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<EPI, MI, false>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (WROWS * 128) : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Deep-ring variant: 256x256 tile, BK = 32, 4 LDS stages of 32 KiB (A 16 KiB + W 16 KiB), 8 waves of 128x64.
 // Three k-steps of LDS-DMA stay in flight (96 KiB per CU) behind counted s_waitcnt vmcnt + raw s_barrier, and the
 // tile carries twice the flops per staged byte of the 128x128 kernel.  Rows are 64 B (4 chunks); the bank swizzle is
@@ -1793,6 +1907,22 @@ static int splitk128_factor(int M, int N, int K, int num_cu) {
     return best;
 }
 
+bool g_conv_implicit = true;
+
+template <int EPI>
+hipError_t launch_conv(const GemmArgs& p, hipStream_t s) {
+    const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch;
+    const size_t lds = (size_t)2 * (128 + 128) * BK * 2;
+    auto k = conv_gemm_kernel<EPI>;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 static int g_gemm_waves = 0;  // 0 = automatic tile choice
 int g_gemm_raster = -1;
 int g_gemm_auto_rule = 2, g_num_cu = 256;
@@ -1889,6 +2019,17 @@ void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
 void gemm_set_splitk128(bool on) { g_gemm_splitk128 = on; }
+void gemm_set_conv_implicit(bool on) { g_conv_implicit = on; }
+bool gemm_conv_implicit() { return g_conv_implicit && g_gemm_glds && g_gemm_waves == 0; }
+// the automatic rule of launch_epi (rule 2) for ONE problem: does it take 256 x 256 tiles (the phased kernel, where K % 128 == 0)?
+bool gemm_auto_takes_256(int M, int N, int K) {
+    if (g_gemm_waves != 0 || g_gemm_auto_rule == 0) return false;
+    const long t256 = (long)((N + 255) / 256) * ((M + 255) / 256);
+    const long rounds = (t256 + g_num_cu - 1) / g_num_cu;
+    const bool fills = t256 * 10 >= rounds * g_num_cu * 9;
+    const bool wide_enough = N >= 4096 || (g_gemm_auto_rule >= 2 && t256 * 100 >= (long)g_num_cu * 85);
+    return N % 256 == 0 && t256 >= 128 && (K >= 2048 || t256 >= 2048 || (wide_enough && fills));
+}
 int gemm_splitk128_factor(int M, int N, int K) { return splitk128_factor(M, N, K, g_num_cu); }
 void gemm_set_early_wait(bool on) { g_gemm_early_wait = on; }
 void gemm_set_persistent_qkv(bool on) { g_gemm_persistent_qkv = on; }
@@ -1939,6 +2080,44 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
                  alg_bytes(p) + alg_bytes(p2));
+    if (p.conv.x) {
+        // implicit-GEMM 3 x 3 convolution on the 128 x 128 kernel (conv_gemm_kernel), split over K by the same rule as below
+        const ConvA& cv = p.conv;
+        if (p2.M > 0 || batch != 1 || (p.epi != EPI_F32 && p.epi != EPI_RESID_F32) || !g_gemm_glds || cv.Cin < 64 || cv.Cin % 64 ||
+            p.K != 9 * cv.Cin || !cv.zero || cv.Ho < 1 || cv.Wo < 1 || p.M % (cv.Ho * cv.Wo) || (p.ldc & 3) ||
+            (reinterpret_cast<uintptr_t>(p.C) & 15))
+            return hipErrorInvalidValue;
+        const int64_t MN = (int64_t)p.M * p.N;
+        int S = 1;
+        if (p.split_ws && g_gemm_splitk128) {
+            S = splitk128_factor(p.M, p.N, p.K, g_num_cu);
+            if ((int64_t)S * MN > p.split_ws_elems) S = 1;
+        }
+        if (S > 1) {
+            GemmArgs q = p;
+            q.K = p.K / S;
+            q.batch = S;
+            q.strideW = q.K;
+            q.bias = nullptr;
+            q.gate = nullptr;
+            q.C = p.split_ws;
+            q.ldc = p.N;
+            q.strideC = MN;
+            q.epi = EPI_F32;
+            q.split_ws = nullptr;
+            const hipError_t e = launch_conv<EPI_F32>(q, s);
+            if (e != hipSuccess) return e;
+            const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
+            if (p.epi == EPI_RESID_F32)
+                hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, (const float*)p.split_ws, S, MN, p.N,
+                                   p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
+            else
+                hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float*)p.split_ws, S, MN, p.N,
+                                   p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
+            return hipGetLastError();
+        }
+        return p.epi == EPI_F32 ? launch_conv<EPI_F32>(p, s) : launch_conv<EPI_RESID_F32>(p, s);
+    }
     if (p.split_ws && g_gemm_splitk128 && g_gemm_waves == 0 && p2.M == 0 && batch == 1 && (p.epi == EPI_F32 || p.epi == EPI_RESID_F32) &&
         (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
         const int S = splitk128_factor(p.M, p.N, p.K, g_num_cu);

@@ -57,6 +57,15 @@ struct QkvEpi {
     const int* seg_tab_host;
 };
 
+// A operand of an implicit-GEMM 3 x 3 convolution (round 5): GEMM row m = output pixel (sample, oy, ox) of nb stacked samples,
+// GEMM column k = (tap, input channel) -- the row of the im2col matrix that is never written.  x: bf16 rows [nb][H*W][Cin],
+// Cin % 64 == 0 (a 64-wide k-tile stays inside one tap); zero: 128 bytes of zeros for taps outside the image.
+struct ConvA {
+    const uint16_t* x;      // null: an ordinary GEMM (GemmArgs::A)
+    const uint16_t* zero;
+    int H, W, Cin, stride, pad, Ho, Wo;
+};
+
 struct GemmArgs {
     const uint16_t* A;  // bf16 [batch][M][K], row stride lda, batch stride strideA (elements)
     int64_t lda, strideA;
@@ -81,6 +90,7 @@ struct GemmArgs {
     // 3 x 3 convolutions at the coarse levels): the caller's workspace for the partial products, null = never split
     float* split_ws;
     int64_t split_ws_elems;
+    ConvA conv;         // conv.x != null: A is the implicit im2col matrix of conv.x (fp32 epilogues, one problem, 128x128 kernel)
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
@@ -95,6 +105,9 @@ void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default off: measured slower)
 void gemm_set_early_wait(bool on);   // persistent phased kernel: the next tile's first k-tile is waited for inside the epilogue (default off: no effect)
+bool gemm_auto_takes_256(int M, int N, int K);   // the automatic tile rule sends one (M, N, K) problem to the 256 x 256 kernels
+void gemm_set_conv_implicit(bool on);   // the texture models' 3 x 3 convolutions gather their A operand themselves (default on) | im2col + GEMM
+bool gemm_conv_implicit();              // ... and the staging path / tile override allow it right now
 void gemm_set_splitk128(bool on);    // split-K of the 128x128 kernel where GemmArgs::split_ws allows it (default on)
 int gemm_splitk128_factor(int M, int N, int K);   // the number of K slices the rule picks for one problem (1 = no split)
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs

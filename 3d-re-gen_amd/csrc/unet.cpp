@@ -51,6 +51,7 @@ struct Unet {
     uint16_t *ctxK = nullptr, *ctxVt = nullptr;
     float *vec = nullptr;                  // [4][max_channels] small vectors
     double* gn_partial = nullptr;
+    const uint16_t* zeros = nullptr;       // 256 bytes of zeros (the implicit convolution's taps outside the image)
     float* splitws = nullptr;              // split-K workspace of the 3 x 3 convolutions (kSplitWsElems floats, GemmArgs::split_ws)
     // whole-model forward (r3g_unet_forward): the concatenated input of an up-block resnet, two hidden-state buffers, the
     // time embedding, and the stack of skip connections (allocated on first use for the resolution at hand)
@@ -144,9 +145,23 @@ static int u_check_shape(const Unet& u, int H, int W, int C, const char* what, i
 static int u_conv3x3(Unet& u, const uint16_t* src, int H, int W, int Cin, int stride, const ULin& l, const float* bias, void* dst,
                      int epi, hipStream_t s, int pad = 1, int nb = 1) {
     const int Ho = (H + pad - 2) / stride + 1, Wo = (W + pad - 2) / stride + 1;
+    const int M = nb * Ho * Wo;
+    // round 5: implicit GEMM -- the 128 x 128 kernel gathers the nine shifted rows itself (conv_gemm_kernel); the im2col matrix is
+    // written only for the problems the tile rule gives to the 256 x 256 kernels (N % 256 == 0 on a grid that fills the chip)
+    if (gemm_conv_implicit() && (epi == EPI_F32 || epi == EPI_RESID_F32) && Cin % 64 == 0 && l.K == 9 * Cin && !gemm_auto_takes_256(M, l.N, l.K)) {
+        GemmArgs p{};
+        p.W = l.w; p.ldw = l.K; p.bias = bias; p.C = dst; p.ldc = l.N;
+        p.M = M; p.N = l.N; p.K = l.K; p.epi = epi;
+        p.split_ws = u.splitws; p.split_ws_elems = kSplitWsElems;
+        p.conv.x = src; p.conv.zero = u.zeros; p.conv.H = H; p.conv.W = W; p.conv.Cin = Cin; p.conv.stride = stride; p.conv.pad = pad;
+        p.conv.Ho = Ho; p.conv.Wo = Wo;
+        hipError_t e = gemm_launch(p, 1, s);
+        if (e != hipSuccess) return hip_fail(e, "gemm_launch(unet implicit convolution)");
+        return R3G_OK;
+    }
     U_TRY(im2col3x3_launch(src, H, W, Cin, stride, pad, u.col, s, nb));       // every sample of the call in one launch
     // few rows over a deep K (the coarse levels): slices of K side by side, summed in a fixed order (gemm.hip: split-K of the 128x128 kernel)
-    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, nb * Ho * Wo, epi, s, u.splitws);
+    return u_gemm(u.col, 9 * (int64_t)Cin, l, bias, dst, l.N, M, epi, s, u.splitws);
 }
 
 // GroupNorm (+ SiLU) per sample of f32 rows [nb][hw][C] -> bf16
@@ -711,7 +726,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
                  o_ck = carve(2 * heads * ckp * 64 * 2), o_cv = carve(2 * heads * ckp * 64 * 2),   /* two contexts: the guidance pair */ o_vec = carve(4 * C * 4),
                  o_gn = carve((int64_t)kMaxViews * (256LL * 256 * 2 * 8 + 256 * 2 * 4)), o_cat = carve(hw * C * 4), o_hb0 = carve(hw * C * 4), o_hb1 = carve(hw * C * 4),
                  o_emb = carve((int64_t)(c.temb_dim + 2 * C) * 4), o_vecn = carve((int64_t)kMaxViews * C * 4),
-                 o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4), o_split = carve(kSplitWsElems * 4);
+                 o_embn = carve((int64_t)kMaxViews * c.temb_dim * 4), o_gate = carve(2 * C * 4), o_split = carve(kSplitWsElems * 4), o_zero = carve(256);
     hipError_t e = hipMalloc((void**)&u->arena, off);
     if (e != hipSuccess) { unet_free(u); return hip_fail(e, "hipMalloc(unet arena)"); }
     e = hipMemset(u->arena, 0, off);      // padded rows must start finite
@@ -724,6 +739,7 @@ static int unet_create(Ctx* ctx, const r3g_unet_config* cfg) {
     u->catbuf = (float*)(a + o_cat); u->hb[0] = (float*)(a + o_hb0); u->hb[1] = (float*)(a + o_hb1); u->emb = (float*)(a + o_emb);
     u->vecn = (float*)(a + o_vecn); u->embn = (float*)(a + o_embn); u->gate = (float*)(a + o_gate);
     u->splitws = (float*)(a + o_split);
+    u->zeros = (const uint16_t*)(a + o_zero);      // the arena is zero-filled above and nothing writes here
     ctx->unet = u;
     return R3G_OK;
 }

@@ -406,7 +406,9 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
- * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "gemm_splitk128" (1 default: the 3 x 3 convolutions of the texture models split a deep k over
+ * operands | 2: MLP only | 3: c_q only -- a different precision, NOT result-preserving), "gemm_splitk" (0), "conv_implicit" (1 default: the 3 x 3 convolutions of the texture models run as implicit GEMMs -- the 128 x 128
+ * kernel gathers the nine shifted rows of its A operand from the activation rows itself, bit-identical to the GEMM over the im2col
+ * matrix | 0: im2col + GEMM, rounds 3-4), "gemm_splitk128" (1 default: the 3 x 3 convolutions of the texture models split a deep k over
  * several workgroups where their grid would fill less than half of the chip, r3g_op_gemm_splitk | 0: one workgroup per tile walks all of k, rounds 2-4 -- another
  * order of the fp32 additions, not bit-preserving), "geo_q_cache_gb" (the
  * budget of geo_q_cache in GiB; < 0, the default: 30 % of the device's memory; a grid that needs more gets a prefix of its passes

@@ -65,6 +65,24 @@ def test_decode_small(small, h, w):
     _check("aekl.decode small %dx%d" % (h, w), small.gpu.decode(z), ref)
 
 
+def test_implicit_convolution_equals_im2col_bit_for_bit(small):
+    """the VAE's convolutions -- among them the encoder's stride-2 Downsample2D with its ONE-SIDED padding F.pad(x, (0, 1, 0, 1)) --
+    as implicit GEMMs (option conv_implicit, the default) against im2col + GEMM: the same bits"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x = torch.randn(1, 3, 64, 32, generator=torch.Generator().manual_seed(21))
+    z = torch.randn(1, 4, 16, 8, generator=torch.Generator().manual_seed(22))
+    got = {}
+    try:
+        for mode in (1, 0):
+            ffi.check(L.r3g_set_option(b"conv_implicit", mode))
+            got[mode] = (small.gpu.encode(x).clone(), small.gpu.decode(z).clone())
+    finally:
+        ffi.check(L.r3g_set_option(b"conv_implicit", 1))
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1])
+
+
 def test_decode_of_encode_round_trip_matches_the_oracles(small):
     """the two passes chained as the pipelines chain them: image -> mode of the latent distribution -> image"""
     import torch

@@ -179,6 +179,37 @@ def test_full_unet_forward_small(h, w, t):
     _check("unet small full forward %dx%d t=%g" % (h, w, t), gpu.forward(x, t, ctx), ref, tol=TOL_MODEL)
 
 
+@pytest.mark.parametrize("h,w", [(16, 12), (5, 7), (24, 20)])
+def test_implicit_convolution_equals_im2col_bit_for_bit(small, h, w):
+    """round 5, option conv_implicit: the 3 x 3 convolutions gather their A operand from the activation rows inside the GEMM kernel
+    (borders, stride 2, the split over K) instead of reading an im2col matrix -- the same fragments in the same k order, so a
+    resnet (two convolutions, stride 1) and a downsampler (stride 2) give the same bits either way"""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    x, temb, ctx = small.inputs(64, h, w, 40 + h)
+    outs = {}
+    try:
+        for mode in (1, 0, 1):
+            ffi.check(L.r3g_set_option(b"conv_implicit", mode))
+            outs[mode] = (small.gpu.resnet("down_blocks.0.resnets.0", x, temb, 64).clone(),
+                          small.gpu.downsample("down_blocks.0.downsamplers.0", x).clone())
+    finally:
+        ffi.check(L.r3g_set_option(b"conv_implicit", 1))
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    # and the whole forward (conv_in with its zero-padded 64 input channels, the up path's convolutions behind the nearest upsampling)
+    from oracle import unet_torch as U
+    oracle, gpu, xf, cf = _full(U.small_config(), 5, 2 * ((h + 1) // 2), 2 * ((w + 1) // 2))
+    try:
+        ffi.check(L.r3g_set_option(b"conv_implicit", 0))
+        a = gpu.forward(xf, 321.0, cf).clone()
+        ffi.check(L.r3g_set_option(b"conv_implicit", 1))
+        b = gpu.forward(xf, 321.0, cf).clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"conv_implicit", 1))
+    assert torch.equal(a, b)
+
+
 def test_full_unet_forward_sd21_dims():
     """the whole SD-2.1-dims UNet (865.9 M parameters, 4 levels, 64x64 latent, 77 x 1024 context), one forward"""
     import time
