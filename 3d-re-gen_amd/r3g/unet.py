@@ -225,6 +225,8 @@ class UnetBlocks(_OwnsContext):
         """sample NCHW [n, in_channels, H, W] (the n views of ONE object) -> NCHW [n, out_channels, H, W]; ctx [1, tokens, dim]
         shared by the views; class_labels: n camera indices or None; flags 1 = keep the states for reference attention
         (the reference pass), 2 = use the registered ones (set_condition)"""
+        if int(flags) & 4:
+            raise ValueError("flag 4 (the guidance pair) needs both contexts stacked: use forward_mv_rows")
         n, cin, h, w = sample.shape
         rows, _, cx = self._in(sample, None, ctx)
         out = torch.empty((n * h * w, self.out_channels), dtype=torch.float32, device=self.device)
@@ -244,6 +246,8 @@ class UnetBlocks(_OwnsContext):
         if out is None:
             out = torch.empty((n * h * w, self.out_channels), dtype=torch.float32, device=self.device)
         lab = None if class_labels is None else (ctypes.c_int32 * n)(*[int(v) for v in class_labels])
+        if (int(flags) & 4) and (ctx_rows.shape[0] % 2 or n % 2):
+            raise ValueError("flag 4 (the guidance pair): an even number of samples and two stacked contexts [2 tokens][ctx_dim]")
         tokens = ctx_rows.shape[0] // 2 if (int(flags) & 4) else ctx_rows.shape[0]
         with torch.cuda.device(self.device):
             _l.check(self.L.r3g_unet_forward_mv(self.ctx, rows.data_ptr(), h, w, ctypes.c_float(float(timestep)), ctx_rows.data_ptr(),

@@ -141,8 +141,11 @@ def test_errors(small):
     x = torch.zeros(3, 4, 8, 8)
     with pytest.raises(ffi.R3GError):
         gpu.gen.forward_mv(torch.zeros(3, 12, 8, 8), 1.0, gpu.text_gen, class_labels=[0, 1, 999])      # camera index out of range
-    with pytest.raises(ffi.R3GError):
-        gpu.gen.forward_mv(torch.zeros(3, 12, 8, 8), 1.0, gpu.text_gen, flags=4)
+    with pytest.raises(ValueError):
+        gpu.gen.forward_mv(torch.zeros(3, 12, 8, 8), 1.0, gpu.text_gen, flags=4)                       # the pair needs two contexts: rows API
+    with pytest.raises(ffi.R3GError):                                                                   # the pair with the reference-pass flag
+        gpu.gen.forward_mv_rows(torch.zeros(4 * 64, 12, device=gpu.gen.device), 4, 8, 8, 1.0,
+                                torch.zeros(2 * gpu.text_gen.shape[1], gpu.text_gen.shape[2], dtype=torch.bfloat16, device=gpu.gen.device), flags=4 | 1)
     with pytest.raises(ffi.R3GError):
         gpu.gen.forward_mv(torch.zeros(13, 12, 16, 16), 1.0, gpu.text_gen)                             # 13 x 256 rows > the arena's 2 x 6 x 256 (a guidance pair of 6 views)
     with pytest.raises(ffi.R3GError):
