@@ -240,3 +240,24 @@ def test_committed_bench_line_has_the_contract_fields():
         assert m["object_like_field"]["frac"] > m["frac"]
         assert r["traffic_stale"] in (True, False) and d["config"]["objects_per_launch"] >= 1
         assert d["steps"] % 1 == 0 and d["config"]["objects_total"] == d["steps"]
+
+
+def test_profiles_index_names_files_that_exist_and_the_headline_line_is_not_stale():
+    """profiles/README.md's tables are the index the review reads: every `rNN_*` file they name is in the directory, and the newest
+    committed bench line was taken with the traffic record of the library it ran (roofline.traffic_stale is False)"""
+    import glob
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "profiles", "README.md")).read()
+    round5 = text.split("## Round 5", 1)[1].split("## Round 4", 1)[0]
+    named = set(re.findall(r"`(r05_[A-Za-z0-9_.]+\.(?:md|json|txt))`", round5)) | {"traffic.json"}
+    assert len(named) >= 15
+    missing = sorted(n for n in named if not os.path.exists(os.path.join(root, "profiles", n)))
+    assert not missing, missing
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench.json")))
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    assert d["roofline"]["traffic_stale"] is False
+    assert d["roofline"]["traffic_source"].startswith("profiles/traffic.json")
+
