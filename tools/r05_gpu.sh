@@ -17,6 +17,7 @@ mkdir -p gpurun_out
 O=gpurun_out
 case "$1" in
 micro)
+    # (tools/ubench binaries: `make -C tools/ubench` in the build container; they travel with the snapshot)
     timeout 120 tools/ubench/mfma_shape 1.0 > $O/r05_mfma_shape.jsonl 2>&1
     timeout 400 python tools/bench_gemm.py --variants 12 --gelu-pk 0,1 --shapes gelu --screen 2 --rounds 5 --iters 10 > $O/r05_gemm_gelu_ab.jsonl 2> $O/r05_gemm_gelu_ab.err
     timeout 300 python tools/bench_attn.py --gens 2,6,8,9 --shapes 0,1,2,3 --rounds 4 --iters 5 > $O/r05_attn_gens.jsonl 2> $O/r05_attn_gens.err
