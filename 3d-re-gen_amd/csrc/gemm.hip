@@ -1487,7 +1487,7 @@ hipError_t launch_gemm8_fp8(const GemmArgs& p, const float* scale_a, const float
 // order among themselves, so "at most six operations outstanding" still implies that every load older than the six newest
 // loads has landed, whatever the stores do.
 template <int EPI, bool EARLY = false>
-__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, int total_tiles) {
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, int total_tiles, int rounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, MI = 8;
     constexpr int HALF = 16384, BUF = 4 * HALF;   // buffer: [A_0][A_1][W_0][W_1]
@@ -1495,7 +1495,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int wg_first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // Tile walk (round 5): an XCD owns ONE contiguous range of the rasterised tile order -- `rounds` tiles per workgroup it hosts --
+    // and its workgroups step through that range side by side (tile = first + local id + step x workgroups of the XCD).  The
+    // range is rows x the 4 tile columns of a raster group, so the group's W panel (2 MiB at K = 1024) stays in the XCD's L2 for
+    // all steps and every A row is fetched once per group; rounds 2-4 gave an XCD a different slice of the order at every step
+    // (tile = first + step x grid) and re-fetched W each time (MLP-in: 403 MB per launch for 70 MB of operands, traffic.json).
+    // rounds == 0 (option "gemm_xcd_walk" 0): rounds 2-4's walk, for A/B.
+    const int xcd_first_wg = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcd_wgs = rounds ? q + (xcd < r ? 1 : 0) : nwg;
+    const int xcd_end = rounds ? min(total_tiles, (xcd_first_wg + xcd_wgs) * rounds) : total_tiles;
+    const int wg_first = (rounds ? min(total_tiles, xcd_first_wg * rounds) : xcd_first_wg) + (orig >> 3);   // < xcd_end (launch_gemm8p: grid = ceil(tiles / rounds))
     const int tiles_a = ((pa.N + BN - 1) / BN) * ((pa.M + BM - 1) / BM) * pa.batch;
     typedef const char __attribute__((address_space(4))) * kernarg_ptr;
     kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1709,8 +1718,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
                 if (pp.bias) bias_pre[j] = *reinterpret_cast<const f32x4*>(pp.bias + (n < pp.N ? n : pp.N - 4));
             }
         }
-        my += nwg;
-        const bool more = my < total_tiles;
+        my += xcd_wgs;
+        const bool more = my < xcd_end;
         if (more) {
             // the next tile's first k-tile goes out before the epilogue and lands under it
             locate_u(my, cur, nk);
@@ -1736,6 +1745,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     }
 }
 
+bool g_gemm_xcd_walk = true;   // persistent kernel: an XCD walks one contiguous range of the tile order (round 5) | 0: rounds 2-4's walk
 bool g_gemm_persistent_qkv = false;  // fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel (measured: +17 ms per object, off)
 bool g_gemm_early_wait = false;  // persistent phased kernel, bf16 outputs: wait for the next tile's first k-tile inside the epilogue (measured: no effect, off)
 
@@ -1756,8 +1766,9 @@ hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipS
             state = hipFuncSetAttribute((const void*)ke, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
     }
     if (state < 0) { (void)hipGetLastError(); return hipErrorNotSupported; }
-    if (kBf16Out && g_gemm_early_wait && p.wide_epilogue) { hipLaunchKernelGGL(ke, dim3(grid), dim3(512), lds, s, p, p2, tiles); }
-    else { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles); }
+    const int walk = g_gemm_xcd_walk ? rounds : 0;
+    if (kBf16Out && g_gemm_early_wait && p.wide_epilogue) { hipLaunchKernelGGL(ke, dim3(grid), dim3(512), lds, s, p, p2, tiles, walk); }
+    else { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles, walk); }
     return hipGetLastError();
 }
 
@@ -2019,6 +2030,7 @@ void gemm_set_persistent(bool on) { g_gemm_persistent = on; }
 void gemm_set_persistent_resid(int mask) { g_gemm_persistent_resid = mask & 3; }
 void gemm_set_splitk(bool on) { g_gemm_splitk = on; }
 void gemm_set_splitk128(bool on) { g_gemm_splitk128 = on; }
+void gemm_set_xcd_walk(bool on) { g_gemm_xcd_walk = on; }
 void gemm_set_conv_implicit(bool on) { g_conv_implicit = on; }
 bool gemm_conv_implicit() { return g_conv_implicit && g_gemm_glds && g_gemm_waves == 0; }
 // the automatic rule of launch_epi (rule 2) for ONE problem: does it take 256 x 256 tiles (the phased kernel, where K % 128 == 0)?

@@ -108,6 +108,7 @@ void gemm_set_early_wait(bool on);   // persistent phased kernel: the next tile'
 bool gemm_auto_takes_256(int M, int N, int K);   // the automatic tile rule sends one (M, N, K) problem to the 256 x 256 kernels
 void gemm_set_conv_implicit(bool on);   // the texture models' 3 x 3 convolutions gather their A operand themselves (default on) | im2col + GEMM
 bool gemm_conv_implicit();              // ... and the staging path / tile override allow it right now
+void gemm_set_xcd_walk(bool on);        // persistent phased kernel: contiguous tile range per XCD (default on)
 void gemm_set_splitk128(bool on);    // split-K of the 128x128 kernel where GemmArgs::split_ws allows it (default on)
 int gemm_splitk128_factor(int M, int N, int K);   // the number of K slices the rule picks for one problem (1 = no split)
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs

@@ -1336,6 +1336,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_splitk")) gemm_set_splitk(value != 0);
     else if (!strcmp(name, "gemm_splitk128")) gemm_set_splitk128(value != 0);
     else if (!strcmp(name, "conv_implicit")) gemm_set_conv_implicit(value != 0);
+    else if (!strcmp(name, "gemm_xcd_walk")) gemm_set_xcd_walk(value != 0);
     else if (!strcmp(name, "gemm_early_wait")) gemm_set_early_wait(value != 0);
     else if (!strcmp(name, "gemm_persistent_qkv")) gemm_set_persistent_qkv(value != 0);
     else if (!strcmp(name, "flow_first_step")) g_flow_first_step = value;
