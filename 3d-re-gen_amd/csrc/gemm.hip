@@ -1496,10 +1496,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     // Tile walk (round 5): an XCD owns ONE contiguous range of the rasterised tile order -- `rounds` tiles per workgroup it hosts --
-    // and its workgroups step through that range side by side (tile = first + local id + step x workgroups of the XCD).  The
-    // range is rows x the 4 tile columns of a raster group, so the group's W panel (2 MiB at K = 1024) stays in the XCD's L2 for
-    // all steps and every A row is fetched once per group; rounds 2-4 gave an XCD a different slice of the order at every step
-    // (tile = first + step x grid) and re-fetched W each time (MLP-in: 403 MB per launch for 70 MB of operands, traffic.json).
+    // and its workgroups step through that range side by side (tile = first + local id + step x workgroups of the XCD): the
+    // range is rows x the 4 tile columns of a raster group, and consecutive steps of an XCD touch neighbouring A rows; rounds 2-4
+    // gave an XCD a different slice of the order at every step (tile = first + step x grid).  Measured on one box (option
+    // "gemm_xcd_walk" 0 / 1, tools/bench_gemm.py): geo c_fc 1 109 -> 1 045 us, 30080 x 3072 bf16 175 -> 172, MLP-in equal.  The
+    // L2 <-> fabric counters do NOT move (MLP-in FETCH_SIZE 197 -> 201 MB raw: the W panel stayed resident under the old walk
+    // too, the bytes are the A rows once per raster group either way) -- the gain is in WHEN the rows are touched, not how often.
     // rounds == 0 (option "gemm_xcd_walk" 0): rounds 2-4's walk, for A/B.
     const int xcd_first_wg = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int xcd_wgs = rounds ? q + (xcd < r ? 1 : 0) : nwg;

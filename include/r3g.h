@@ -399,7 +399,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * persistent grid | 13 = phased, deterministic split-K over two workgroups per tile | 16 | 32 = deep ring), "gemm_raster" (-1 auto | tile columns per rasterisation group), "gemm_phased"
  * (1: 256x256 tiles on the phased counted-vmcnt kernel), "gemm_persistent" (1: its persistent form for bf16 outputs
  * with more tiles than CUs), "gemm_xcd_walk" (1 default: in the persistent form an XCD's workgroups walk ONE contiguous range of the
- * rasterised tile order, so a raster group's W panel stays in that XCD's L2 -- geo c_fc 1 109 -> 1 045 us; bit-identical | 0: rounds 2-4's walk), "gemm_persistent_resid" (0 | bit 0: the fp32, bit 1: the bf16 read-modify-write epilogue on the persistent form as well), "gemm_num_cu" (CUs the tile rules assume, default 256), "gemm_auto_rule" (2: the current
+ * rasterised tile order (consecutive steps touch neighbouring A rows) -- geo c_fc 1 109 -> 1 045 us, L2 <-> fabric bytes unchanged; bit-identical | 0: rounds 2-4's walk), "gemm_persistent_resid" (0 | bit 0: the fp32, bit 1: the bf16 read-modify-write epilogue on the persistent form as well), "gemm_num_cu" (CUs the tile rules assume, default 256), "gemm_auto_rule" (2: the current
  * tile-choice rule | 1: round 2's | 0: round 1's first version), "attn_generation" (7 default: 6 where its
  * 256-query workgroups make four rounds of the device, otherwise 2 | 2 = four waves of 32 queries | 6 = four waves of 64
  * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_wide_min" (2048: work items of 256 queries from which attn_generation 7 takes generation 6), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
