@@ -574,6 +574,39 @@ __device__ __forceinline__ float half_sum(float x) {
 }
 
 constexpr float PSUM_LIMIT = 1024.f;   // (pipelined body) a block whose 16 p of one lane sum to more is re-stabilised
+// Round 6 variants of the generation-2 / generation-6 bodies (template VAR, option "attn_variant"; profiles/r06_attention.md):
+//  bit 0  after the first key block (whose exact maximum starts the stabiliser) the FAST pass takes no maximum at all: the 8 v_max3,
+//         the compare and the branch per key block leave the common path, and a key tile becomes one basic block.  The stabiliser
+//         only has to keep exp2 inside the fp32 range, so the test is on the lane's SUM of its 16 exponentials (which the row sum
+//         needs anyway) against a generous bound (2^16, or NaN) and only sets a sticky flag; when a VALID query of the workgroup
+//         set it, the whole query tile runs again as the SAFE pass = variant 0's body, and nothing of the fast pass is used.
+//         Without a re-stabilisation the results are bit-identical to variant 0; a tile that takes the safe pass is bit-identical
+//         to it too; where variant 0 would have moved the stabiliser (a score more than 8 above it) and the fast pass does not
+//         (sum <= 2^16), P is rounded at another scale: equal within the bf16 rounding of P.
+//  bit 1  the row sum on plain v_add_f32 in the packed form's association order (bit-identical): MI355X_MICROARCH.md prices a
+//         v_pk_add_f32 beside MFMAs above two plain adds.
+constexpr float PSUM_LIMIT2 = 65536.f;
+__device__ __forceinline__ float add_f32_plain(float a, float b) {   // an add the SLP vectoriser cannot pack
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// sum of 16 values in the order of the packed-pair form: (((e0 + e2) + ... + e14) + ((o1 + o3) + ... + o15))
+template <bool PLAIN>
+__device__ __forceinline__ float sum16(const float (&pe)[16]) {
+    if constexpr (PLAIN) {
+        float a = pe[0], b = pe[1];
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) { a = add_f32_plain(a, pe[r]); b = add_f32_plain(b, pe[r + 1]); }
+        return add_f32_plain(a, b);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        f2 ps = (f2){pe[0], pe[1]};
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) ps += (f2){pe[r], pe[r + 1]};
+        return ps[0] + ps[1];
+    }
+}
 constexpr float SCORE_LIMIT = 8.f;     // a block with a score more than 8 (log2 units) above its stabiliser (p > 256) is re-stabilised
 
 // D = A B + C with D in registers DISTINCT from C (hipcc ties vdst to srcC for the builtin and copies the 16 registers
@@ -593,7 +626,7 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_fresh(const bf16x8& a, const bf1
 // the loop, 32 no per-tile wait + barrier, 64 no V^T reads, 128 no K reads); results are garbage for ABL != 0.
 // (Round 5 also tried this body at FOUR waves per SIMD -- four workgroups per compute unit, registers capped at 128: 22 spilled
 // registers inside the key loop, 905 against 995 TFLOP/s on the geo decoder's passes; profiles/r05_attention_phases.md.)
-template <bool GLDS, bool PIPE, int NW, int ABL = 0>
+template <bool GLDS, bool PIPE, int NW, int ABL = 0, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[(PIPE ? 3 : 2) * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -807,6 +840,16 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
         if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1, slot);
         else tile(std::false_type{}, std::false_type{}, ntiles - 1, slot);
     } else {
+    // variant bit 0 (round 6, comment at PSUM_LIMIT2): the FAST pass takes no maximum after the first key block -- a lane whose 16
+    // exponentials sum past the bound (or to NaN) only sets a sticky flag -- and when a valid query of the workgroup set it, the
+    // whole query tile runs again as the SAFE pass (the body of variant 0, bit for bit); nothing of the fast pass is used then.
+    unsigned long long sticky = 0;
+    auto pass = [&](auto FAST) __attribute__((always_inline)) {
+    constexpr bool kFast = decltype(FAST)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    m_run = 0.f;
+    l_run = 0.f;
     stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -862,14 +905,17 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
             // the scores, all by arithmetic on themselves) and nothing computed on it is merged with a value of the common
             // path afterwards -- with the test behind the exponentials (on their sum) the join copied 16 exponentials
             // and the 16-register stabiliser block on the common path of every key block (32 v_mov)
-            float mx = fmaxf(s[0], s[1]);
+            float mx = 0.f;
+            if (first_block || !kFast) {
+                mx = fmaxf(s[0], s[1]);
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+                for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+            }
             if (first_block) {   // the stabiliser starts as the exact maximum of the first 32 keys
                 m_run = half_max(mx);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { negm[r] = -m_run; s[r] -= m_run; }
-            } else if (__any(q < Lq && !(mx <= SCORE_LIMIT))) {
+            } else if (!kFast && __any(q < Lq && !(mx <= SCORE_LIMIT))) {
                 // (rows past Lq hold stale data: they must not decide anything, or a valid query's rounding would depend on it)
                 // rare: some query's scores outgrew its stabiliser (or are NaN).  s is relative to the old one: the growth
                 // is the block maximum itself.  Nothing of this block has entered O or l yet.
@@ -886,11 +932,10 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
             for (int r = 0; r < 16; ++r) pe[r] = (ABL & 1) ? s[r] * 0.001f : __builtin_amdgcn_exp2f(s[r]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
-            {
-                f32x2 ps = (f32x2){pe[0], pe[1]};   // even / odd partial sums on the packed fp32 adder
-#pragma unroll
-                for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
-                l_run += ps[0] + ps[1];
+            {   // even / odd partial sums: packed fp32 adder, or (variant bit 1) plain adds in the same order
+                const float psum = sum16<(VAR & 2) != 0>(pe);
+                l_run += psum;
+                if (kFast && !first_block) sticky |= __ballot(q < Lq && !(psum <= PSUM_LIMIT2));
             }
             // ---- O^T += V^T P^T for these 32 keys: the lane's 8 keys of each 16-key group are one 16-byte chunk of V^T
 #pragma unroll
@@ -920,6 +965,13 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
         for (int t = 1; t < ntiles - 1; ++t) tile(std::false_type{}, std::false_type{}, t);
         if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1);
         else tile(std::false_type{}, std::false_type{}, ntiles - 1);
+    }
+    };   // pass
+    if constexpr ((VAR & 1) != 0 && ABL == 0) {
+        pass(std::true_type{});
+        if (__syncthreads_or(sticky != 0)) pass(std::false_type{});   // workgroup-uniform: all waves stage the second pass's tiles
+    } else {
+        pass(std::false_type{});
     }
     }   // !PIPE
 
@@ -958,7 +1010,7 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
 // L2 -> LDS stream per query, and the two blocks give every MFMA chain an independent neighbour.  Two workgroups of four
 // waves per CU (256 registers per lane).  Per 32-query block the arithmetic, the order of the key blocks and the
 // re-stabilise decisions (taken per aligned group of 32 queries) are those of attn2_kernel: the outputs are bit-identical.
-template <int NW>
+template <int NW, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1006,11 +1058,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     }
 
     f32x16 o[2][2], negm[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
-    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    float m_run[2], l_run[2];
+    // variant bit 0 (round 6, comment at PSUM_LIMIT2): the FAST pass takes no maximum after the first key block; a lane whose 16
+    // exponentials sum past the bound (or to NaN) only sets a sticky flag.  When a valid query of the workgroup set it, the whole
+    // query tile runs again as the SAFE pass -- generation 2's body with its test on the lane maxima, bit-identical to variant 0 --
+    // and nothing of the fast pass is used.  (An in-place rare path as in attn2_kernel costs this 256-register kernel a spilled Q
+    // fragment inside the key loop, whose reload waits on vmcnt(0) -- i.e. on the LDS-DMA prefetch.)
+    unsigned long long sticky = 0;
 
     int off[2];
 #pragma unroll
@@ -1044,6 +1098,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
         }
     };
     const bool pad_tail = ntiles * KV_TILE > Lk;
+    auto pass = [&](auto FAST) __attribute__((always_inline)) {
+    constexpr bool kFast = decltype(FAST)::value;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
+        m_run[qb] = 0.f;
+        l_run[qb] = 0.f;
+    }
     stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1088,14 +1151,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
                         else if (key == bias_key) sq[r] += bias_l2;
                     }
                 }
-                float mx = fmaxf(sq[0], sq[1]);
+                float mx = 0.f;
+                if (first_block || !kFast) {
+                    mx = fmaxf(sq[0], sq[1]);
 #pragma unroll
-                for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sq[r]), sq[r + 1]);
+                    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sq[r]), sq[r + 1]);
+                }
                 if (first_block) {
                     m_run[qb] = half_max(mx);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { negm[qb][r] = -m_run[qb]; sq[r] -= m_run[qb]; }
-                } else if (__any(q0 + qb * 32 < Lq && !(mx <= SCORE_LIMIT))) {   // rows past Lq (stale data) decide nothing
+                } else if (!kFast && __any(q0 + qb * 32 < Lq && !(mx <= SCORE_LIMIT))) {   // rows past Lq (stale data) decide nothing
                     const float grow = fmaxf(half_max(mx), 0.f);
                     const float alpha = __builtin_amdgcn_exp2f(-grow);
                     m_run[qb] += grow;
@@ -1113,10 +1179,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(sq[r]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pk[qb][e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
-                f32x2 ps = (f32x2){pe[0], pe[1]};
-#pragma unroll
-                for (int r = 2; r < 16; r += 2) ps += (f32x2){pe[r], pe[r + 1]};
-                l_run[qb] += ps[0] + ps[1];
+                const float psum = sum16<(VAR & 2) != 0>(pe);
+                l_run[qb] += psum;
+                if (kFast && !first_block) sticky |= __ballot(q0 + qb * 32 < Lq && !(psum <= PSUM_LIMIT2));
             }
             // ---- O^T += V^T P^T: one V^T fragment feeds both query blocks
 #pragma unroll
@@ -1145,6 +1210,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
         for (int t = 1; t < ntiles - 1; ++t) tile(std::false_type{}, std::false_type{}, t);
         if (pad_tail) tile(std::true_type{}, std::false_type{}, ntiles - 1);
         else tile(std::false_type{}, std::false_type{}, ntiles - 1);
+    }
+    };   // pass
+    if constexpr ((VAR & 1) != 0) {
+        pass(std::true_type{});
+        // (the last tile's closing barrier has passed: every wave is done with the LDS tiles; the vote is workgroup-uniform
+        // because all four waves stage the tiles of the second pass and meet at its barriers)
+        if (__syncthreads_or(sticky != 0)) pass(std::false_type{});
+    } else {
+        pass(std::false_type{});
     }
 
 #pragma unroll
@@ -1450,6 +1524,8 @@ void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 
 static int g_attn_gen = 7;
+static int g_attn_variant = 1;     // option "attn_variant" (round 6): bit 0 fast pass without a maximum + sticky sum test (default), bit 1 plain adds (generations 2 / 6 / 7)
+void attn_set_variant(int v) { if (v >= 0 && v <= 3) g_attn_variant = v; }
 // generation 7 takes the 64-query-per-wave kernel where its 256-query workgroups make at least four full rounds of the
 // 512 slots (the geo decoder's 131072-query passes: +6 %); on the DiT's 4442-query attention the coarser grid costs more
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
@@ -1544,8 +1620,21 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         else if (gen == 3) hipLaunchKernelGGL((attn2_kernel<true, true, 4>), dim3(items), dim3(256), 0, s, p);
         else if (gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
-        else if (gen == 6) hipLaunchKernelGGL((attn3_kernel<4>), dim3(items), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
+        else if (gen == 6) {
+            switch (g_attn_variant) {
+                case 1: hipLaunchKernelGGL((attn3_kernel<4, 1>), dim3(items), dim3(256), 0, s, p); break;
+                case 2: hipLaunchKernelGGL((attn3_kernel<4, 2>), dim3(items), dim3(256), 0, s, p); break;
+                case 3: hipLaunchKernelGGL((attn3_kernel<4, 3>), dim3(items), dim3(256), 0, s, p); break;
+                default: hipLaunchKernelGGL((attn3_kernel<4, 0>), dim3(items), dim3(256), 0, s, p); break;
+            }
+        } else {
+            switch (g_attn_variant) {
+                case 1: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 1>), dim3(items), dim3(256), 0, s, p); break;
+                case 2: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 2>), dim3(items), dim3(256), 0, s, p); break;
+                case 3: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 3>), dim3(items), dim3(256), 0, s, p); break;
+                default: hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p); break;
+            }
+        }
         return hipGetLastError();
     }
     if (p.q_prescaled) return hipErrorInvalidValue;   // the first-generation kernels scale the scores themselves

@@ -84,11 +84,19 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 // PI: 16-row groups per pass through the scratch (PI * 16 rows x 128 bytes of LDS per wave; PI = MI: one pass).
 // VM0: s_waitcnt vmcnt(0) before the first global store (the persistent kernel issues the next tile's LDS-DMA before this
 // epilogue and wants it landed, but must not wait for the epilogue's own stores afterwards).
-template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false>
+// SLICE: byte distance between the 16-row groups (2 KiB each) of a scratch made of 128-byte rows.  2048 = one contiguous block
+// (every kernel but the persistent one); the persistent kernel (round 6) passes 16384: the four groups of a 64-row pass are the
+// wave's OWN 2 KiB staging slices in the four regions of k-tile buffer 1, which is idle between the last k-tile of a tile and
+// the staging of the next tile's k-tile 1 -- and which only this wave's LDS-DMA overwrites, so no workgroup barrier is owed.
+template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false, int SLICE = 2048>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
                                               int wc, int lane, char* lds_wave = nullptr, const f32x4* bias_pre = nullptr) {
     constexpr int WROWS = MI * 16;
     static_assert(MI % PI == 0, "scratch passes");
+    static_assert(SLICE == 2048 || ((EPI == EPI_QKV || EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) && PI == 4),
+                  "sliced scratch: 64-row passes of 128-byte rows");
+    // byte offset of row R of a scratch of 128-byte rows
+    auto roff = [](int R) __attribute__((always_inline)) { return SLICE == 2048 ? R * 128 : (R >> 4) * SLICE + (R & 15) * 128; };
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 columns are exactly one head of q, k or v.  Lane holds, for row m = .. + i*16 + (lane&15),
         // head dims d = j*16 + (lane>>4)*4 + {0..3}; the other dims of that row sit in lanes lane^16, lane^32, lane^48.
@@ -176,7 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     int ob;
                     int64_t drow;
                     if (!map_row(mw + rr, ob, drow)) continue;
-                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
                     uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
                                                 : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
                     *reinterpret_cast<uint4*>(base + cc * 8) = dv;
@@ -191,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
                     const int u = ck >> 1, h8 = (ck & 1) * 8;
                     const int sw = (d >> 2) & (CPR - 1);
-                    const char* drow_lds = lds_wave + d * (PROWS * 2);
+                    const char* drow_lds = lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2));
                     const uint2 lo = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u) ^ sw) << 4) + h8);
                     const uint2 hi = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
                     const int mfirst = mw + 16 * u;
@@ -270,7 +278,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         pk.x = pack_bf16(v[j][0], v[j][1]);
                         pk.y = pack_bf16(v[j][2], v[j][3]);
                         const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
-                        *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
+                        *reinterpret_cast<uint2*>(lds_wave + roff(r) + chunk * 16 + (q & 1) * 8) = pk;
                     }
                 } else {
 #pragma unroll
@@ -279,7 +287,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         for (int c = 0; c < 4; ++c) {
                             const int d = j * 16 + q * 4 + c;
                             const int chunk = (r >> 3) ^ ((d >> 2) & (PROWS / 8 - 1));
-                            *reinterpret_cast<uint16_t*>(lds_wave + d * (PROWS * 2) + chunk * 16 + (r & 7) * 2) =
+                            *reinterpret_cast<uint16_t*>(lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2)) + chunk * 16 + (r & 7) * 2) =
                                 (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
                         }
                 }
@@ -575,7 +583,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         pk.y = pack_bf16(v[2], v[3]);
                         const int r = ii * 16 + (lane & 15), q = lane >> 4;
                         const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
-                        *reinterpret_cast<uint2*>(lds_wave + r * 128 + chunk * 16 + (q & 1) * 8) = pk;
+                        *reinterpret_cast<uint2*>(lds_wave + roff(r) + chunk * 16 + (q & 1) * 8) = pk;
                     } else if (n < p.N && m < p.M) {
                         const int64_t off = cbase + (int64_t)m * p.ldc + n;
                         if (EPI == EPI_F32) {
@@ -598,7 +606,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 for (int t = 0; t < PI * 2; ++t) {
                     const int rr = t * 8 + (lane >> 3);
                     const int m = m0 + wr * WROWS + ip * 16 + rr;
-                    const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
                     if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
                 }
                 if (PI != MI) {
@@ -1479,14 +1487,18 @@ hipError_t launch_gemm8_fp8(const GemmArgs& p, const float* scale_a, const float
 // kernel; this form removes most of the prologue and part of the epilogue wait (bf16 outputs -2 .. -9 %).  The fp32
 // read-modify-write epilogue is bound by HBM (1.3 GB per launch at ~3.5 TB/s) and stays on gemm8_kernel.
 // Same k-order and MFMA shape as gemm8_kernel: bit-identical results.
-// EARLY (round 4, bf16-output epilogues): the wait for the next tile's first k-tile sits inside the epilogue, in front of its
-// first global store (the pieces were issued before the epilogue began and have had its arithmetic to land), and the loop is
-// entered WITHOUT a vmcnt: round 3's vmcnt(6) at the loop top also waited for the acknowledgements of the epilogue's stores,
-// which are older than the six pieces of k-tile 1 (stamps: 2-5 k cycles per tile).  The first counted wait of the k-loop
-// (phase 4) retires k-tile 1 and the stores together, ~2 k cycles later.  Safe with stores in the count: loads complete in
-// order among themselves, so "at most six operations outstanding" still implies that every load older than the six newest
-// loads has landed, whatever the stores do.
-template <int EPI, bool EARLY = false>
+// (Round 4's EARLY variant -- the wait for the next tile's first k-tile inside the epilogue -- measured "no effect" and left the
+// library in round 6 together with its option.)
+// SLICED (round 6, bf16-output and fused-QKV epilogues): the epilogue's LDS transpose runs in 64-row passes through the wave's own
+// staging slices of k-tile buffer 1 (gemm_epilogue's SLICE) instead of 32-row passes through 4 KiB of extra scratch: two passes
+// per tile instead of four, V^T rows leave as whole 128-byte lines.  Buffer 1 is idle then: its last reader passed the k-loop's
+// closing barriers, the next tile's k-tile 0 goes to buffer 0, and k-tile 1 is staged after the epilogue -- by every wave into
+// its OWN slices only, behind its own LDS reads (lgkmcnt is waited for before the stores those reads feed), so there is no
+// cross-wave hazard and no extra barrier.
+// EPI2 (round 6): the epilogue of the SECOND problem's tiles when two problems with different epilogues share the launch -- a
+// single block's linear1 = [fused QKV | MLP-in + GELU] over the same rows is 1 416 + 1 888 tiles = 12.9 rounds of 256 CUs in ONE
+// grid where the two launches took 6 + 8 (their last rounds 53 % / 92 % full).  The tile's problem is wave-uniform.
+template <int EPI, bool SLICED = false, int EPI2 = EPI>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, int total_tiles, int rounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, MI = 8;
@@ -1683,13 +1695,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     locate_u(my, cur, nk);
     set_sources(cur);
     stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
-    bool first_tile = true;
     for (;;) {
         // k-tile 0 is on its way (and, after the first tile, the previous tile's stores); k-tile 1 follows as in gemm8_kernel.
         // vmcnt(6) retires everything older than these six pieces -- exact whatever the epilogue issued.
         stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
-        if (!EARLY || first_tile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        first_tile = false;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         R3G_BAR();
         if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
         int t = 0;
@@ -1730,10 +1740,23 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         }
         {
             const GemmArgs& pp = args_of(done.second);
-            gemm_epilogue<EPI, MI, true, 2, EARLY>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
-                                                   pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr,
-                                                   (EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) ? bias_pre : nullptr);
-            // (last tile: no next k-tile was staged, the wait inside the epilogue found nothing -- harmless)
+            auto run = [&](auto E) __attribute__((always_inline)) {
+                constexpr int epi = decltype(E)::value;
+                constexpr bool kPre = epi == EPI_BF16 || epi == EPI_BF16_GELU_TANH || epi == EPI_BF16_GELU_ERF;
+                constexpr bool kSl = SLICED && (kPre || epi == EPI_QKV);
+                if constexpr (kSl)
+                    gemm_epilogue<epi, MI, true, 4, false, HALF>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
+                                                                 pp.wide_epilogue ? smem + BUF + wid * 2048 : nullptr, kPre ? bias_pre : nullptr);
+                else
+                    gemm_epilogue<epi, MI, true, 2, false>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
+                                                           pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr, kPre ? bias_pre : nullptr);
+            };
+            if constexpr (EPI2 != EPI) {
+                if (done.second) run(std::integral_constant<int, EPI2>{});
+                else run(std::integral_constant<int, EPI>{});
+            } else {
+                run(std::integral_constant<int, EPI>{});
+            }
         }
         if (!more) break;
         // the staging pointers are recomputed rather than kept alive across the epilogue (16 registers it needs); the
@@ -1749,27 +1772,29 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
 
 bool g_gemm_xcd_walk = true;   // persistent kernel: an XCD walks one contiguous range of the tile order (round 5) | 0: rounds 2-4's walk
 bool g_gemm_persistent_qkv = false;  // fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel (measured: +17 ms per object, off)
-bool g_gemm_early_wait = false;  // persistent phased kernel, bf16 outputs: wait for the next tile's first k-tile inside the epilogue (measured: no effect, off)
+bool g_gemm_epi_slices = true;   // persistent kernel, bf16 / fused-QKV epilogues: 64-row passes through the wave's slices of k-tile buffer 1 (round 6) | 0: 32-row passes
+bool g_gemm_mixed = true;        // a single block's [fused QKV | MLP-in + GELU] as ONE persistent launch (round 6) | 0: two launches
 
-template <int EPI>
+// EPI2 != EPI: p2 is a problem with another epilogue (gemm8p_kernel's EPI2)
+template <int EPI, int EPI2 = EPI>
 hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipStream_t s) {
     int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256) * p.batch;
     if (p2.M > 0) tiles += ((p2.N + 255) / 256) * ((p2.M + 255) / 256) * p2.batch;
     const int rounds = (tiles + num_cu - 1) / num_cu;
     const int grid = (tiles + rounds - 1) / rounds;    // every workgroup gets `rounds` tiles (the last ones one fewer)
     const size_t lds = 163840;
-    constexpr bool kBf16Out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_QKV;
-    auto k = gemm8p_kernel<EPI, false>;
-    auto ke = gemm8p_kernel<EPI, kBf16Out>;
+    constexpr bool kSliceable = EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_QKV;
+    auto k = gemm8p_kernel<EPI, false, EPI2>;
+    auto ks = gemm8p_kernel<EPI, kSliceable, EPI2>;
     static int state = 0;   // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS
     if (state == 0) {
         state = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
-        if (state > 0 && kBf16Out)
-            state = hipFuncSetAttribute((const void*)ke, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+        if (state > 0 && kSliceable)
+            state = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
     }
     if (state < 0) { (void)hipGetLastError(); return hipErrorNotSupported; }
     const int walk = g_gemm_xcd_walk ? rounds : 0;
-    if (kBf16Out && g_gemm_early_wait && p.wide_epilogue) { hipLaunchKernelGGL(ke, dim3(grid), dim3(512), lds, s, p, p2, tiles, walk); }
+    if (kSliceable && g_gemm_epi_slices && p.wide_epilogue) { hipLaunchKernelGGL(ks, dim3(grid), dim3(512), lds, s, p, p2, tiles, walk); }
     else { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p, p2, tiles, walk); }
     return hipGetLastError();
 }
@@ -2045,7 +2070,8 @@ bool gemm_auto_takes_256(int M, int N, int K) {
     return N % 256 == 0 && t256 >= 128 && (K >= 2048 || t256 >= 2048 || (wide_enough && fills));
 }
 int gemm_splitk128_factor(int M, int N, int K) { return splitk128_factor(M, N, K, g_num_cu); }
-void gemm_set_early_wait(bool on) { g_gemm_early_wait = on; }
+void gemm_set_epi_slices(bool on) { g_gemm_epi_slices = on; }
+void gemm_set_mixed(bool on) { g_gemm_mixed = on; }
 void gemm_set_persistent_qkv(bool on) { g_gemm_persistent_qkv = on; }
 void gemm_set_config(int waves) {
     if (waves == 0 || waves == 4 || waves == 8 || waves == 9 || waves == 10 || waves == 11 || waves == 12 || waves == 13 || waves == 16 || waves == 32) g_gemm_waves = waves;
@@ -2175,6 +2201,37 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
 }
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s) { return gemm_launch2(p, batch, nullptr, 0, s); }
+
+// A DiT single block's linear1 (upstream: ONE Linear H -> 3H + mlp_hidden): the fused QKV projection and the MLP-in + GELU(tanh)
+// projection read the same rows.  Round 6: both problems as ONE persistent launch of the phased kernel (gemm8p_kernel's EPI2) when
+// that grid fills the machine -- 1 416 + 1 888 tiles of 256 x 256 are 12.9 rounds of 256 CUs where the two launches took 6 + 8 --
+// otherwise the two launches of rounds 1-5 (MLP-in first).  Same tiles, same k order: bit-identical either way.
+hipError_t gemm_launch_qkv_mlp(const GemmArgs& pq_in, const GemmArgs& pm_in, hipStream_t s) {
+    GemmArgs pq = pq_in, pm = pm_in;
+    auto fallback = [&]() {
+        const hipError_t e = gemm_launch(pm_in, 1, s);
+        return e != hipSuccess ? e : gemm_launch(pq_in, 1, s);
+    };
+    if (!g_gemm_mixed || !g_gemm_persistent || !g_gemm_phased || g_gemm_waves != 0 || !g_gemm_glds || !g_gemm_wide_epilogue ||
+        pq.epi != EPI_QKV || pm.epi != EPI_BF16_GELU_TANH || pq.conv.x || pm.conv.x || pq.M <= 0 || pm.M <= 0)
+        return fallback();
+    if (pq.K % 128 || pm.K % 128 || pq.K < 256 || pm.K < 256 || pq.N % 256 || pm.N % 256) return fallback();
+    const long tiles = (long)(pq.N / 256) * ((pq.M + 255) / 256) + (long)(pm.N / 256) * ((pm.M + 255) / 256);
+    const long rounds = (tiles + g_num_cu - 1) / g_num_cu;
+    if (tiles < 2L * g_num_cu || tiles * 10 < rounds * g_num_cu * 9) return fallback();   // the grid must fill >= 90 % of its rounds
+    for (GemmArgs* g : {&pq, &pm}) {
+        g->batch = 1;
+        g->raster_group = g_gemm_raster;
+        g->wide_epilogue = 1;
+        g->gelu_pk = g_gemm_gelu_pk ? 1 : 0;
+        if (!gemm_args_ok(*g)) return hipErrorInvalidValue;
+    }
+    auto alg_bytes = [](const GemmArgs& g) { return 2.0 * g.M * g.K + 2.0 * (double)g.M * g.N + 2.0 * (double)g.N * g.K; };
+    ProfScope ps(PC_GEMM, 2.0 * (double)pq.M * pq.N * pq.K + 2.0 * (double)pm.M * pm.N * pm.K, s, alg_bytes(pq) + alg_bytes(pm));
+    const hipError_t e = launch_gemm8p<EPI_QKV, EPI_BF16_GELU_TANH>(pq, pm, g_num_cu, s);
+    if (e == hipErrorNotSupported) return fallback();
+    return e;
+}
 
 // FP8 operands: A8 [M][K] and W8 [N][K] bytes (e4m3), one fp32 scale per row of each.  K % 256 == 0, lda / ldw in bytes.
 hipError_t gemm_fp8_launch(const GemmArgs& p_in, const float* scale_a, const float* scale_w, hipStream_t s) {

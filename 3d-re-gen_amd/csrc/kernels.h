@@ -99,12 +99,16 @@ hipError_t gemm_launch2(const GemmArgs& p, int batch, const GemmArgs* p2, int ba
 void gemm_set_glds(bool on);  // staging path: LDS-DMA (default) or register-staged
 void attn_set_glds(bool on);
 void attn_set_ablate(int mask);   // timing-only ablation builds of the attention kernel (tools/bench_attn.py)
+void attn_set_variant(int v);       // round 6: bit 0 re-stabilise test on the sum of the exponentials, bit 1 row sum on plain adds (generations 2 / 6 / 7)
 void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off by default: slower) vs the plain one
 void gemm_set_config(int waves);   // tile kernel: 0 automatic | 4 | 8 | 9 | 10 | 11 | 12 | 13 | 16 | 32 (include/r3g.h)
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
 void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default off: measured slower)
-void gemm_set_early_wait(bool on);   // persistent phased kernel: the next tile's first k-tile is waited for inside the epilogue (default off: no effect)
+void gemm_set_epi_slices(bool on);   // persistent phased kernel: bf16 / fused-QKV epilogues in 64-row passes through the wave's slices of k-tile buffer 1 (default on)
+void gemm_set_mixed(bool on);        // a single block's [fused QKV | MLP-in + GELU] as one persistent launch (default on)
+// fused QKV projection (pq, EPI_QKV) and MLP-in + GELU(tanh) (pm) over the same rows: one launch when the grid fills the machine
+hipError_t gemm_launch_qkv_mlp(const GemmArgs& pq, const GemmArgs& pm, hipStream_t s);
 bool gemm_auto_takes_256(int M, int N, int K);   // the automatic tile rule sends one (M, N, K) problem to the 256 x 256 kernels
 void gemm_set_conv_implicit(bool on);   // the texture models' 3 x 3 convolutions gather their A operand themselves (default on) | im2col + GEMM
 bool gemm_conv_implicit();              // ... and the staging path / tile override allow it right now

@@ -648,11 +648,15 @@ static int dit_forward_cfg_dedup(Model& m, const float* x_lat, float t_scalar, f
             R3G_TRY(hipStreamWaitEvent(m.aux, m.ev_fork, 0));
             sm = m.aux;
         }
-        R3G_RC(gemm(d.xn, H, 0, l, 3 * H, mh, d.cat + H, catld, 0, Rall, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, sm));
         if (overlap) {
+            R3G_RC(gemm(d.xn, H, 0, l, 3 * H, mh, d.cat + H, catld, 0, Rall, H, EPI_BF16_GELU_TANH, nullptr, 0, 1, sm));
             R3G_TRY(hipEventRecord(m.ev_join, m.aux));
         } else {
-            R3G_RC(launch_qkv());
+            // linear1 as upstream has it -- one projection over [q k v | mlp-in] -- where the combined grid fills the machine
+            // (round 6, gemm_launch_qkv_mlp); otherwise the two launches of rounds 1-5
+            const GemmArgs pm = gemm_args(d.xn, H, 0, l, 3 * H, mh, d.cat + H, catld, 0, Rall, H, EPI_BF16_GELU_TANH, nullptr, 0);
+            hipError_t e1 = gemm_launch_qkv_mlp(pq, pm, s);
+            if (e1 != hipSuccess) return hip_fail(e1, "gemm_launch_qkv_mlp");
         }
         hipError_t e = attention_launch(at, s);
         if (e != hipSuccess) return hip_fail(e, "attention_launch(dedup)");
@@ -1337,7 +1341,9 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_splitk128")) gemm_set_splitk128(value != 0);
     else if (!strcmp(name, "conv_implicit")) gemm_set_conv_implicit(value != 0);
     else if (!strcmp(name, "gemm_xcd_walk")) gemm_set_xcd_walk(value != 0);
-    else if (!strcmp(name, "gemm_early_wait")) gemm_set_early_wait(value != 0);
+    else if (!strcmp(name, "attn_variant")) attn_set_variant(value);
+    else if (!strcmp(name, "gemm_epi_slices")) gemm_set_epi_slices(value != 0);
+    else if (!strcmp(name, "gemm_mixed")) gemm_set_mixed(value != 0);
     else if (!strcmp(name, "gemm_persistent_qkv")) gemm_set_persistent_qkv(value != 0);
     else if (!strcmp(name, "flow_first_step")) g_flow_first_step = value;
     else if (!strcmp(name, "flow_last_step")) g_flow_last_step = value < 0 ? (1 << 30) : value;

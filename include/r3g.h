@@ -423,8 +423,15 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * phases, work and barrier wait, per launch to stderr -- timing experiments, synchronous), "dit_f16_guard" (1 default: the final latents of a launch group that ran
  * on the fp16 stream are checked for NaN / infinity and a group that overflowed runs again on the fp32 stream, with a line on
  * stderr | 0: no check),
- * "gemm_early_wait" (0 default | 1: the persistent phased kernel waits for the next tile's first k-tile inside the bf16 epilogue, in
- * front of its first store, and enters the k-loop without waiting for the epilogue's store acknowledgements -- measured: no effect), "gemm_persistent_qkv" (0 default | 1: fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel,
+ * "attn_variant" (round 6; generations 2 / 6 / 7: bit 0 -- default on -- the FAST pass takes no maximum after the first key block and
+ * tests the sum of a lane's 16 exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its query
+ * tile again with variant 0's body; bit 1 -- the row sum on plain v_add_f32 instead of the packed adder, same order; 0 = rounds
+ * 2-5.  Bit-identical to variant 0 unless variant 0 would have moved its stabiliser where the fast pass does not: then equal
+ * within the bf16 rounding of P),
+ * "gemm_epi_slices" (1 default, round 6 | 0: the persistent phased kernel's bf16 / fused-QKV epilogues in 32-row passes through 4 KiB of
+ * extra scratch per wave instead of 64-row passes through the wave's own staging slices of the idle k-tile buffer), "gemm_mixed" (1
+ * default, round 6 | 0: a DiT single block's fused QKV projection and MLP-in + GELU projection as two launches instead of one
+ * persistent launch over both problems' tiles), "gemm_persistent_qkv" (0 default | 1: fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel,
  * their epilogue in passes of 32 rows -- measured 17 ms per object slower, profiles/r04_gemm_stream.md), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive
  * segments continuing on each other's latents are the same launches as one call -- how tests read the latents after 10, 20, ...
  * of 50 steps).  None of them changes a

@@ -285,6 +285,29 @@ def test_objects_sharing_a_launch_get_bit_identical_results(which, n, tiny, wide
             assert torch.equal(c[o], st.gpu.flow_sample(lat[o].clone(), cond_nu[o], 2, 2.0))
 
 
+def test_linear1_as_one_persistent_launch_and_sliced_epilogues_are_bit_identical(wide):
+    """Round 6: at four objects per launch a single block's [fused QKV | MLP-in + GELU] runs as ONE persistent launch of the phased
+    kernel (option gemm_mixed; the QKV tiles' epilogue on the persistent kernel, in 64-row passes through the wave's slices of the
+    idle k-tile buffer: option gemm_epi_slices).  Same tiles, same k order: every combination of the two options gives the same bits."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    lat, cond = _batch_inputs(wide, 4, 300)
+    want = wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0).clone()
+    try:
+        for mixed, slices in ((0, 1), (1, 0), (0, 0)):
+            ffi.check(L.r3g_set_option(b"gemm_mixed", mixed))
+            ffi.check(L.r3g_set_option(b"gemm_epi_slices", slices))
+            got = wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0)
+            assert torch.equal(got, want), "gemm_mixed=%d gemm_epi_slices=%d: max |d| %.3e" % (
+                mixed, slices, float((got - want).abs().max()))
+    finally:
+        ffi.check(L.r3g_set_option(b"gemm_mixed", 1))
+        ffi.check(L.r3g_set_option(b"gemm_epi_slices", 1))
+    for _ in range(2):                                   # stable from run to run (an LDS hazard would show as rare diffs)
+        assert torch.equal(wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0), want)
+
+
 def test_pipeline_takes_a_list_of_images():
     """upstream's batch dimension: pipe(image=[...]) -> one mesh per image; with one generator per image every object is
     what its own single-image call gives (grids bit-identical, hence meshes identical)"""

@@ -306,6 +306,65 @@ def test_attention_forced_rescale(env, gen):
     assert torch.allclose(o.float()[0, 5], vrows[0, 0, 400], atol=3e-2)
 
 
+def _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, shared, gen, variant):
+    o = torch.zeros(B, Lq, H * 64, device="cuda", dtype=torch.bfloat16)
+    ffi.check(L.r3g_set_option(b"attn_generation", gen))
+    ffi.check(L.r3g_set_option(b"attn_variant", variant))
+    try:
+        ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp, shared, 1,
+                                     stream(torch)))
+        torch.cuda.synchronize()
+    finally:
+        ffi.check(L.r3g_set_option(b"attn_generation", 7))
+        ffi.check(L.r3g_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    return o
+
+
+ATTN_VARIANT_DEFAULT = 1    # the library's default (csrc/attn.hip g_attn_variant); the tests restore it
+
+
+@pytest.mark.parametrize("gen", [2, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_attention_variants_without_a_maximum_in_the_common_path(env, gen, variant):
+    """Round 6, option attn_variant: bit 0 = the fast pass takes no maximum after the first key block and tests the SUM of a lane's
+    exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its tile again with variant 0's body.
+    bit 1 = the row sum on plain adds in the packed form's order.  (a) random data: no re-stabilisation either way, so the same
+    bits as variant 0; (b) a key 46 log2 units above everything late in the sequence: the safe pass runs, the same bits again;
+    (c) a key ~12 units above: variant 0 moves its stabiliser, the fast pass does not -- equal within the bf16 rounding of P;
+    (d) stale query rows past Lq with huge values set no flag and change no bit."""
+    torch, L, ffi = env
+    from r3g.layout import read_vt
+    for (B, H, Lq, Lk, shared) in [(1, 2, 200, 200, 0), (2, 16, 4442, 4442, 0), (3, 4, 500, 3072, 1), (1, 2, 300, 129, 0)]:
+        Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, shared, Lq + 5 * Lk)
+        a = _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, shared, gen, 0)
+        b = _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, shared, gen, variant)
+        assert rel_l2(b.float(), ref) <= 1e-2
+        assert torch.equal(a, b), "random data, %s: max |d| %.3e" % ((B, H, Lq, Lk), float((a.float() - b.float()).abs().max()))
+    B, H, Lq, Lk = 1, 1, 128, 512
+    for factor, same_bits in ((4.0, True), (1.04, False)):
+        Q, K, Vt, _, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, 0, 11)
+        K[0, 0, 400] = (Q[0, 0, 5].float() * factor).to(torch.bfloat16)
+        vrows = read_vt(Vt, Lk).float()
+        ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :Lq].float(), K[:, :, :Lk].float(), vrows)
+        ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, 64)
+        a = _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, 0, gen, 0)
+        b = _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, 0, gen, variant)
+        assert torch.isfinite(b.float()).all()
+        assert rel_l2(b.float(), ref) <= 1e-2 and rel_l2(a.float(), ref) <= 1e-2
+        if same_bits:
+            assert torch.equal(a, b)
+            assert torch.allclose(b.float()[0, 5], vrows[0, 0, 400], atol=3e-2)
+    B, H, Lq, Lk = 1, 2, 200, 300
+    Q, K, Vt, ref, lqp, lkp = _attn_case(torch, B, H, Lq, Lk, 0, 5)
+    outs = []
+    for junk in (0.0, 40.0, -40.0):
+        Q[:, :, Lq:] = junk
+        outs.append(_attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, 0, gen, variant))
+    assert rel_l2(outs[0].float(), ref) <= 1e-2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], _attn_run(torch, L, ffi, Q, K, Vt, B, H, Lq, lqp, Lk, lkp, 0, gen, 0))
+
+
 @pytest.mark.parametrize("epi,flavour,other", [(1, "tanh", "erf"), (2, "erf", "tanh")])
 def test_gelu_flavour_is_the_stated_one(env, epi, flavour, other):
     """tanh- and erf-GELU differ by <= 4.7e-4: less than the bf16 step of most outputs, so no rel-L2 can tell them apart

@@ -84,7 +84,7 @@ def test_whole_evaluation_small(small, n_views, n_ref, hw, scales):
     assert rel_l2(got, indep) > 5 * e                          # the cross-view / reference branches are not a rounding effect
 
 
-@pytest.mark.parametrize("n_views,hw", [(6, 16), (3, 8)])
+@pytest.mark.parametrize("n_views,hw", [(6, 16), (3, 8), (1, 8)])   # (1, 8): one view per half -- no multiview attention in either form
 def test_guidance_pair_in_one_launch_set_equals_the_two_calls(small, n_views, hw):
     """r3g_unet_forward_mv flag 4 (round 5): the conditional evaluation (learned context, reference attention) and the unconditional one
     (zero context, no reference attention) of a guided step as ONE launch set of 2 n samples -- every sample's prediction is the

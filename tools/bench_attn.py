@@ -31,7 +31,13 @@ def main():
     ap.add_argument("--gen", type=int, default=2, help="kernel generation the ablation masks apply to")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (clock / power sensitivity)")
     a = ap.parse_args()
-    masks = [int(m) for m in (a.gens or a.ablate).split(",")]
+    # --gens entries: "G" or "GvV" = attn_generation G with attn_variant V (round 6), e.g. 2v0,2v1,2v3,6v0,6v1
+    def parse(m):
+        if "v" in m:
+            g_, v_ = m.split("v")
+            return int(g_) * 10 + int(v_) + 1000
+        return int(m)
+    masks = [parse(m) for m in (a.gens or a.ablate).split(",")]
     ffi.context(0)
     L = ffi.lib()
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -50,7 +56,11 @@ def main():
 
         def run(mask):
             if a.gens:
-                ffi.check(L.r3g_set_option(b"attn_generation", mask))
+                if mask >= 1000:
+                    ffi.check(L.r3g_set_option(b"attn_generation", (mask - 1000) // 10))
+                    ffi.check(L.r3g_set_option(b"attn_variant", (mask - 1000) % 10))
+                else:
+                    ffi.check(L.r3g_set_option(b"attn_generation", mask))
             else:
                 ffi.check(L.r3g_set_option(b"attn_ablate", mask))
             ffi.check(L.r3g_op_attention(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), o.data_ptr(), B, H, Lq, lqp, Lk, lkp,
@@ -85,6 +95,7 @@ def main():
                                   tflops_med=fl / med / 1e9)), flush=True)
     ffi.check(L.r3g_set_option(b"attn_ablate", 0))
     ffi.check(L.r3g_set_option(b"attn_generation", 7))
+    ffi.check(L.r3g_set_option(b"attn_variant", 1))
 
 
 if __name__ == "__main__":
