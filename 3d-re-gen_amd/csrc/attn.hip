@@ -583,29 +583,18 @@ constexpr float PSUM_LIMIT = 1024.f;   // (pipelined body) a block whose 16 p of
 //         Without a re-stabilisation the results are bit-identical to variant 0; a tile that takes the safe pass is bit-identical
 //         to it too; where variant 0 would have moved the stabiliser (a score more than 8 above it) and the fast pass does not
 //         (sum <= 2^16), P is rounded at another scale: equal within the bf16 rounding of P.
-//  bit 1  the row sum on plain v_add_f32 in the packed form's association order (bit-identical): MI355X_MICROARCH.md prices a
-//         v_pk_add_f32 beside MFMAs above two plain adds.
+// (A second variant bit -- the row sum on plain v_add_f32 through inline asm, because MI355X_MICROARCH.md prices a v_pk_add_f32 beside
+// MFMAs above two plain adds -- measured +2 % on both kernels and was REMOVED: the compiler does not see that an inline-asm add
+// reads the result of a v_exp_f32 issued just before it (the transcendental-use hazard needs a wait state it only inserts for
+// instructions it knows), and the 64-query kernel produced wrong sums; profiles/r06_attention.md.)
 constexpr float PSUM_LIMIT2 = 65536.f;
-__device__ __forceinline__ float add_f32_plain(float a, float b) {   // an add the SLP vectoriser cannot pack
-    float d;
-    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// sum of 16 values in the order of the packed-pair form: (((e0 + e2) + ... + e14) + ((o1 + o3) + ... + o15))
-template <bool PLAIN>
+// sum of 16 values as even / odd partial sums on the packed fp32 adder: (((e0 + e2) + ... + e14) + ((o1 + o3) + ... + o15))
 __device__ __forceinline__ float sum16(const float (&pe)[16]) {
-    if constexpr (PLAIN) {
-        float a = pe[0], b = pe[1];
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 ps = (f2){pe[0], pe[1]};
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) { a = add_f32_plain(a, pe[r]); b = add_f32_plain(b, pe[r + 1]); }
-        return add_f32_plain(a, b);
-    } else {
-        typedef __attribute__((ext_vector_type(2))) float f2;
-        f2 ps = (f2){pe[0], pe[1]};
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) ps += (f2){pe[r], pe[r + 1]};
-        return ps[0] + ps[1];
-    }
+    for (int r = 2; r < 16; r += 2) ps += (f2){pe[r], pe[r + 1]};
+    return ps[0] + ps[1];
 }
 constexpr float SCORE_LIMIT = 8.f;     // a block with a score more than 8 (log2 units) above its stabiliser (p > 256) is re-stabilised
 
@@ -690,23 +679,26 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     // staging: this lane's two 16-byte chunks of a K tile and of a V^T tile; the per-lane element offsets do not depend on
     // the tile (wave-uniform tile base + constant lane offset: no vector address arithmetic inside the loop)
     constexpr int PPW = 8 / NW;   // 1 KiB pieces (8 tile rows) of each of the two tiles per wave
-    int koff[PPW], voff[PPW];
+    // (round 6: BYTE offsets as unsigned 32-bit values -- wave-uniform tile base + zero-extended lane offset is the scalar-base
+    // form of the LDS-DMA load, so a key tile costs no 64-bit vector address arithmetic; a V^T row offset stays below 2^32 bytes
+    // for any Lk_pad this kernel is launched with: 64 rows x Lk_pad x 2 bytes)
+    uint32_t koff[PPW], voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int row = (wid * PPW + i) * 8 + (lane >> 3);
         const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        koff[i] = row * 64 + kc * 8;
-        voff[i] = row * p.Lk_pad + kc * 8;
+        koff[i] = (uint32_t)(row * 64 + kc * 8) * 2u;
+        voff[i] = ((uint32_t)row * (uint32_t)p.Lk_pad + (uint32_t)(kc * 8)) * 2u;
     }
     auto stage = [&](int t, char* dst) {
         if constexpr (GLDS) {
-            const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
-            const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
+            const char* kt = reinterpret_cast<const char*>(Kg + (int64_t)t * (KV_TILE * 64));
+            const char* vt = reinterpret_cast<const char*>(Vtg + (int64_t)t * KV_TILE);
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff[i]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + (size_t)koff[i]),
                                                  (__attribute__((address_space(3))) void*)(dst + (wid * PPW + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff[i]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + (size_t)voff[i]),
                                                  (__attribute__((address_space(3))) void*)(dst + TILE_B + (wid * PPW + i) * 1024),
                                                  16, 0, 0);
             }
@@ -844,6 +836,7 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
     // exponentials sum past the bound (or to NaN) only sets a sticky flag -- and when a valid query of the workgroup set it, the
     // whole query tile runs again as the SAFE pass (the body of variant 0, bit for bit); nothing of the fast pass is used then.
     unsigned long long sticky = 0;
+    const unsigned long long valid_lanes = __ballot(q < Lq);   // rows past Lq (stale data) set no flag
     auto pass = [&](auto FAST) __attribute__((always_inline)) {
     constexpr bool kFast = decltype(FAST)::value;
 #pragma unroll
@@ -933,9 +926,9 @@ __global__ __launch_bounds__(NW * 64, (PIPE || NW == 8) ? 2 : 3) void attn2_kern
 #pragma unroll
             for (int e = 0; e < 8; ++e) pk[e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
             {   // even / odd partial sums: packed fp32 adder, or (variant bit 1) plain adds in the same order
-                const float psum = sum16<(VAR & 2) != 0>(pe);
+                const float psum = sum16(pe);
                 l_run += psum;
-                if (kFast && !first_block) sticky |= __ballot(q < Lq && !(psum <= PSUM_LIMIT2));
+                if (kFast && !first_block) sticky |= __ballot(!(psum <= PSUM_LIMIT2)) & valid_lanes;
             }
             // ---- O^T += V^T P^T for these 32 keys: the lane's 8 keys of each 16-key group are one 16-byte chunk of V^T
 #pragma unroll
@@ -1065,6 +1058,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     // and nothing of the fast pass is used.  (An in-place rare path as in attn2_kernel costs this 256-register kernel a spilled Q
     // fragment inside the key loop, whose reload waits on vmcnt(0) -- i.e. on the LDS-DMA prefetch.)
     unsigned long long sticky = 0;
+    const unsigned long long valid_lanes[2] = {__ballot(q0 < Lq), __ballot(q0 + 32 < Lq)};   // rows past Lq (stale data) set no flag
 
     int off[2];
 #pragma unroll
@@ -1077,22 +1071,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     const int bias_key = en.bias_key;
     const float bias_l2 = p.ragged ? en.bias_log2 : 0.f;
     constexpr int PPW = 8 / NW;
-    int koff[PPW], voff[PPW];
+    uint32_t koff[PPW], voff[PPW];     // byte offsets, unsigned: scalar tile base + zero-extended lane offset (see attn2_kernel)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int row = (wid * PPW + i) * 8 + (lane >> 3);
         const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        koff[i] = row * 64 + kc * 8;
-        voff[i] = row * p.Lk_pad + kc * 8;
+        koff[i] = (uint32_t)(row * 64 + kc * 8) * 2u;
+        voff[i] = ((uint32_t)row * (uint32_t)p.Lk_pad + (uint32_t)(kc * 8)) * 2u;
     }
     auto stage = [&](int t, char* dst) {
-        const uint16_t* kt = Kg + (int64_t)t * (KV_TILE * 64);
-        const uint16_t* vt = Vtg + (int64_t)t * KV_TILE;
+        const char* kt = reinterpret_cast<const char*>(Kg + (int64_t)t * (KV_TILE * 64));
+        const char* vt = reinterpret_cast<const char*>(Vtg + (int64_t)t * KV_TILE);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + koff[i]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + (size_t)koff[i]),
                                              (__attribute__((address_space(3))) void*)(dst + (wid * PPW + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + voff[i]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + (size_t)voff[i]),
                                              (__attribute__((address_space(3))) void*)(dst + TILE_B + (wid * PPW + i) * 1024),
                                              16, 0, 0);
         }
@@ -1179,9 +1173,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(sq[r]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pk[qb][e] = pack_bf16(pe[2 * e], pe[2 * e + 1]);
-                const float psum = sum16<(VAR & 2) != 0>(pe);
+                const float psum = sum16(pe);
                 l_run[qb] += psum;
-                if (kFast && !first_block) sticky |= __ballot(q0 + qb * 32 < Lq && !(psum <= PSUM_LIMIT2));
+                if (kFast && !first_block) sticky |= __ballot(!(psum <= PSUM_LIMIT2)) & valid_lanes[qb];
             }
             // ---- O^T += V^T P^T: one V^T fragment feeds both query blocks
 #pragma unroll
@@ -1524,8 +1518,8 @@ void attn_set_glds(bool on) { g_attn_glds = on; }
 void attn_set_pipelined(bool on) { g_attn_pipelined = on; }
 
 static int g_attn_gen = 7;
-static int g_attn_variant = 1;     // option "attn_variant" (round 6): bit 0 fast pass without a maximum + sticky sum test (default), bit 1 plain adds (generations 2 / 6 / 7)
-void attn_set_variant(int v) { if (v >= 0 && v <= 3) g_attn_variant = v; }
+static int g_attn_variant = 1;     // option "attn_variant" (round 6): 1 = fast pass without a maximum + sticky sum test (default) | 0 = rounds 2-5 (generations 2 / 6 / 7)
+void attn_set_variant(int v) { if (v >= 0 && v <= 1) g_attn_variant = v; }
 // generation 7 takes the 64-query-per-wave kernel where its 256-query workgroups make at least four full rounds of the
 // 512 slots (the geo decoder's 131072-query passes: +6 %); on the DiT's 4442-query attention the coarser grid costs more
 // than the kernel gains (576 workgroups on 512 slots), profiles/r02_attention.md
@@ -1621,19 +1615,11 @@ hipError_t attention_launch(const AttnArgs& p, hipStream_t s) {
         else if (gen == 4) hipLaunchKernelGGL((attn2_kernel<true, true, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 5) hipLaunchKernelGGL((attn2_kernel<true, false, 8>), dim3(items), dim3(512), 0, s, p);
         else if (gen == 6) {
-            switch (g_attn_variant) {
-                case 1: hipLaunchKernelGGL((attn3_kernel<4, 1>), dim3(items), dim3(256), 0, s, p); break;
-                case 2: hipLaunchKernelGGL((attn3_kernel<4, 2>), dim3(items), dim3(256), 0, s, p); break;
-                case 3: hipLaunchKernelGGL((attn3_kernel<4, 3>), dim3(items), dim3(256), 0, s, p); break;
-                default: hipLaunchKernelGGL((attn3_kernel<4, 0>), dim3(items), dim3(256), 0, s, p); break;
-            }
+            if (g_attn_variant == 1) hipLaunchKernelGGL((attn3_kernel<4, 1>), dim3(items), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((attn3_kernel<4, 0>), dim3(items), dim3(256), 0, s, p);
         } else {
-            switch (g_attn_variant) {
-                case 1: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 1>), dim3(items), dim3(256), 0, s, p); break;
-                case 2: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 2>), dim3(items), dim3(256), 0, s, p); break;
-                case 3: hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 3>), dim3(items), dim3(256), 0, s, p); break;
-                default: hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p); break;
-            }
+            if (g_attn_variant == 1) hipLaunchKernelGGL((attn2_kernel<true, false, 4, 0, 1>), dim3(items), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((attn2_kernel<true, false, 4>), dim3(items), dim3(256), 0, s, p);
         }
         return hipGetLastError();
     }

@@ -61,6 +61,7 @@ static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached 
 static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_dit_f16_guard = true;    // option "dit_f16_guard": check the latents of an fp16-stream group, fall back to fp32 on overflow
+static int64_t g_dit_groups = 0;         // launch groups r3g_flow_sample_batch has run (r3g_get_counter)
 static int g_dit_f16_fallbacks = 0;    // how often that happened (r3g_set_option("dit_f16_fallbacks_reset", ...) / stderr line)
 static bool g_dit_resid_f16 = true;   // the DiT's residual stream of the de-duplicated CFG path in fp16 (the reference's activation type) instead of fp32
 static bool g_skip_zero_step = true;   // skip the DiT evaluation of a step whose d_sigma is 0 (upstream's last step)
@@ -1158,6 +1159,7 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
         // stream -- never silently wrong latents from a checkpoint whose activations outgrow fp16.
         const bool guard = g_dit_resid_f16 && m->H % 256 == 0 && g_dit_f16_guard;
         if (guard) R3G_TRY(hipMemcpyAsync(d.lat0, lat, (size_t)NB * n * 4, hipMemcpyDeviceToDevice, s));
+        ++g_dit_groups;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool allow_f16 = attempt == 0;
             for (int i = std::max(0, g_flow_first_step); i < std::min(steps, g_flow_last_step); ++i) {
@@ -1181,6 +1183,14 @@ static int flow_sample(Model* m, float* d_latents, const uint16_t* d_cond2, int 
             R3G_TRY(hipMemcpyAsync(lat, d.lat0, (size_t)NB * n * 4, hipMemcpyDeviceToDevice, s));
         }
     }
+    return R3G_OK;
+}
+
+int r3g_get_counter(const char* name, int64_t* value) {
+    if (!name || !value) return fail(R3G_ERR_INVALID, "r3g_get_counter: null argument");
+    if (!strcmp(name, "dit_f16_fallbacks")) *value = g_dit_f16_fallbacks;
+    else if (!strcmp(name, "dit_groups")) *value = g_dit_groups;
+    else return fail(R3G_ERR_INVALID, "r3g_get_counter: unknown counter '%s'", name);
     return R3G_OK;
 }
 

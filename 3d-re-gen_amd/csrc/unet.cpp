@@ -189,7 +189,9 @@ static int unet_resnet(Unet& u, const std::string& pre, const float* x, int H, i
     U_RC(u_lin(u, pre + ".conv2", true, Cout, 9 * Cout, &c2));
     // per-channel constant of conv1's epilogue: conv1.bias + time_emb_proj(silu(temb))
     const float* cb = c1.b;
-    const bool per_sample = temb && nb > 1 && temb_stride != 0;
+    // (per-sample embeddings -- class labels -- take this path for ONE sample too: a guidance pair of one view per half (nb = 2) must
+    // equal its two calls (nb = 1) bit for bit, and "bias + projection folded into conv1's epilogue" associates the fp32 sum the other way)
+    const bool per_sample = temb && temb_stride != 0;
     if (temb) {
         U_RC(u_lin(u, pre + ".time_emb_proj", true, Cout, u.c.temb_dim, &tp));
         if (per_sample) {

@@ -26,6 +26,109 @@ import torch
 import torch.distributed as dist
 
 
+def init_process_group(backend, rank=None, world_size=None, device=None, timeout_s=None):
+    """dist.init_process_group with a collective timeout (round 6): a collective a dead peer never joins raises after
+    `timeout_s` seconds (R3G_DIST_TIMEOUT_S, default 300) instead of holding the job until the launcher's own limit.  `device`
+    (a torch.device) pins the RCCL communicator to this rank's GPU."""
+    import datetime
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("R3G_DIST_TIMEOUT_S", "300"))
+    kw = {"timeout": datetime.timedelta(seconds=float(timeout_s))}
+    if rank is not None:
+        kw["rank"] = rank
+    if world_size is not None:
+        kw["world_size"] = world_size
+    if device is not None and backend == "nccl":
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+
+
+class Watchdog:
+    """A rank that dies or hangs must end the JOB, with a message that names it, well inside the launcher's limit (round 6; the
+    reference's pool simply loses the task, src/2d_to_3d_models/run.py:176-193).
+
+    Every rank's main thread calls beat(phase) whenever it makes progress (a launch group done, a gather done); a daemon
+    thread publishes {time of the last beat, phase} under hb/<rank> in the side store every `interval_s` and reads the other
+    ranks' records.  A peer whose last beat is older than `limit_s` -- or whose record stops arriving because its process is gone,
+    or the store itself when rank 0 is gone -- is reported on stderr by every surviving rank ("rank 3: no progress from rank 5 for
+    104 s, last phase 'weak: launch group 2'") and the process leaves with exit code 17 (os._exit: the main thread may be parked
+    inside a collective that will never complete).  torch.distributed.run then tears the other ranks down.  done() ends the
+    supervision of this rank (its record says so: a rank that finished early is not a hung rank).
+
+    The thread talks to the store through a client connection of its own; collective on construction (side_store())."""
+
+    EXIT_CODE = 17
+
+    def __init__(self, limit_s=None, interval_s=None, on_fail=None):
+        import threading
+        import time
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.limit = float(os.environ.get("R3G_WATCHDOG_LIMIT_S", "100")) if limit_s is None else float(limit_s)
+        self.interval = min(5.0, self.limit / 4) if interval_s is None else float(interval_s)
+        self._time = time
+        self._last = (time.time(), "start")
+        self._done = False
+        self._on_fail = on_fail
+        store = side_store()
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self._client = dist.TCPStore(host, int(store.port), self.world, is_master=False, wait_for_workers=False)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="r3g-watchdog", daemon=True)
+        self._thread.start()
+
+    def beat(self, phase):
+        self._last = (self._time.time(), str(phase))
+
+    def done(self):
+        self._done = True
+        self._last = (self._time.time(), "done")
+        try:
+            self._publish()
+        except Exception:
+            pass
+        self._stop.set()
+
+    def _publish(self):
+        t, ph = self._last
+        self._client.set("hb/%d" % self.rank, json.dumps({"t": t, "phase": ph, "done": self._done}))
+
+    def _fail(self, msg):
+        import sys
+        print("[r3g watchdog] rank %d: %s -- ending the job (exit code %d)" % (self.rank, msg, self.EXIT_CODE), file=sys.stderr, flush=True)
+        if self._on_fail is not None:
+            self._on_fail(msg)
+            return
+        os._exit(self.EXIT_CODE)
+
+    def _run(self):
+        started = self._time.time()
+        store_down_since = None
+        while not self._stop.wait(self.interval):
+            now = self._time.time()
+            try:
+                self._publish()
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue
+                    key = "hb/%d" % r
+                    if not self._client.check([key]):
+                        if now - started > self.limit:
+                            return self._fail("rank %d never reported (%.0f s since start)" % (r, now - started))
+                        continue
+                    rec = json.loads(self._client.get(key).decode())
+                    if rec.get("done"):
+                        continue
+                    if now - float(rec["t"]) > self.limit:
+                        return self._fail("no progress from rank %d for %.0f s, last phase '%s'" % (r, now - float(rec["t"]), rec.get("phase")))
+                store_down_since = None
+            except Exception as e:       # the store is served by rank 0's process
+                if self._stop.is_set():
+                    return
+                store_down_since = store_down_since or now
+                if now - store_down_since > min(self.limit, 30.0):
+                    return self._fail("the side store (rank 0's process) does not answer for %.0f s: %s" % (now - store_down_since, e))
+
+
 def _comm_device():
     """tensors handed to collectives live in HBM under RCCL and on the host under gloo"""
     if dist.get_backend() == "nccl":

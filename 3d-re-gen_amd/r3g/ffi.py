@@ -82,6 +82,7 @@ SYMBOLS = {
     "r3g_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "r3g_set_staging": (_I, [_I]),
     "r3g_set_option": (_I, [ctypes.c_char_p, _I]),
+    "r3g_get_counter": (_I, [ctypes.c_char_p, _P]),
     "r3g_prof_enable": (_I, [_I]),
     "r3g_prof_read": (_I, [_P, _P, _P, _I]),
     "r3g_prof_read_bytes": (_I, [_P, _I]),
@@ -142,6 +143,13 @@ def check(rc):
     if rc == R3G_ERR_NO_SURFACE:
         raise NoSurfaceError(msg)
     raise R3GError(rc, msg)
+
+
+def counter(name):
+    """r3g_get_counter: a process-wide event counter of the library ("dit_f16_fallbacks", "dit_groups")"""
+    v = ctypes.c_int64(0)
+    check(lib().r3g_get_counter(name.encode(), ctypes.byref(v)))
+    return int(v.value)
 
 
 def new_context(device=0):

@@ -356,8 +356,16 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
     rank_error = None
     shapegen = texgen = None
     claimed = []
+    # a rank that dies or hangs ends the stage with a message that names it (r3g/dist.py Watchdog; `r3g_watchdog_s`: seconds
+    # without progress -- model load included -- after which a rank counts as lost, default 300; 0 = no watchdog)
+    wd_limit = float(config.get("r3g_watchdog_s", 300))
+    wd = rdist.Watchdog(limit_s=wd_limit) if wd_limit > 0 else None
     try:
+        if wd is not None:
+            wd.beat("loading the models")
         shapegen, texgen, cleaners = factory(config, device)
+        if wd is not None:
+            wd.beat("models loaded")
 
         def images_of(idx):
             return [Image.fromarray(crops[i].cpu().numpy(), "RGBA") for i in idx]
@@ -390,6 +398,8 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
                 else:
                     print("ERROR in worker for '%s' on rank %d: %s" % (os.path.basename(image_paths[i]), rank, err))
                     status.append((i, image_paths[i], "error: %s" % err, secs, rank))
+            if wd is not None:
+                wd.beat("%d objects done, last '%s'" % (len(status), bases[-1]))
             claimed = nxt if nxt else queue.claim_guided(B, world)
     except Exception as e:      # rank-level failure: keep what is finished, report what was in flight, stay collective
         rank_error = e
@@ -400,6 +410,8 @@ def run_distributed(config, input_folder, output_folder, rank, world, factory):
                 status.append((i, image_paths[i], "error: rank %d failed: %s" % (rank, e), 0.0, rank))
     if shapegen is not None and hasattr(shapegen, "close_prefetch"):
         shapegen.close_prefetch()
+    if wd is not None:
+        wd.done()           # (a rank that waits for the others in the gather below is finished, not hung)
     ok_flags = rdist.all_ok(rank_error is None)
     failed_ranks = [r for r, ok in enumerate(ok_flags) if not ok]
     local = []
@@ -464,10 +476,8 @@ def main(argv=None, factory=default_factory):
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     from r3g import dist as rdist
-    if torch.cuda.is_available():
-        dist.init_process_group(backend, device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
-    else:
-        dist.init_process_group(backend)
+    # (collective timeout, R3G_DIST_TIMEOUT_S: a collective a dead peer never joins raises instead of waiting for ever)
+    rdist.init_process_group(backend, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() else None)
     rc = 0
     try:
         if rank == 0 and not os.environ.get("R3G_STAGE_PREPARED"):
@@ -510,6 +520,14 @@ def report(results, textured=True):
         rep["texture_load_problems"] = list(LOAD_PROBLEMS)
     if results and len(results[0]) > 4:
         rep["rank_of_object"] = [r[4] for r in results]
+    try:
+        # launch groups of THIS process (rank 0 of a distributed run) whose fp16 residual stream overflowed and that ran again on
+        # the fp32 stream (r3g_get_counter): such a group takes twice its time -- a slow stage says why
+        from r3g import ffi
+        rep["dit_f16_fallbacks"] = ffi.counter("dit_f16_fallbacks")
+        rep["dit_groups"] = ffi.counter("dit_groups")
+    except Exception:       # (the CPU-only API-contract tests run this script without the library)
+        pass
     print(json.dumps(rep))
     return rep
 

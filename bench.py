@@ -26,8 +26,8 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                  over one further object: achieved = sum of algorithmic FLOPs / sum of launch durations
   roofline_mc  : the HBM-bound kernel of the path (marching cubes): algorithmic bytes 4 (R+1)^3 + 12 V + 12 F over its
                  measured time, against the 8 TB/s HBM peak
-  cpu_baseline : the PyTorch-CPU fp32 oracle + the C marching-cubes oracle timed on this box's host cores on a
-                 bounded sample of the same workload and extrapolated (rank 0, N=1 only)
+  cpu_baseline : the PyTorch-CPU oracle (fp32 = `value`, and bf16 under autocast beside it) + the C marching-cubes oracle timed on
+                 this box's host cores on a bounded sample of the same workload and extrapolated (rank 0, N=1 only)
   mc_parity    : the last timed object's mesh (faces AND float32 vertices) against the C oracle's mesh of the same grid,
                  computed for the CPU baseline anyway: "exact" or the run fails
 """
@@ -118,7 +118,9 @@ HOST_THREADS = torch.get_num_threads()   # (256 hardware threads oversubscribe t
 
 
 def cpu_baseline(cfg, steps, R, grid_np):
-    """Oracle (PyTorch CPU fp32 restatement + C marching cubes) on a bounded sample, extrapolated to one object."""
+    """Oracle (PyTorch CPU restatement + C marching cubes) on a bounded sample, extrapolated to one object: fp32 (the parity
+    oracle's own arithmetic; `value`) and bf16 beside it (the same modules under torch.autocast("cpu", bfloat16): matrix products and
+    attention in bf16, norms / softmax statistics in fp32 -- what an AMX / AVX512-bf16 host runs fastest)."""
     from oracle import hy3d_torch as H
     from oracle import mc as omc
     torch.set_num_threads(HOST_THREADS)             # torch's own choice for this host (its physical cores), whatever ran before
@@ -130,30 +132,12 @@ def cpu_baseline(cfg, steps, R, grid_np):
     x = torch.randn(2, v["num_latents"], d["in_channels"])
     cond = torch.randn(2, Lc, d["context_in_dim"])
     t = torch.tensor([0.5, 0.5])
-
-    spent = [0.0]
-
-    def tm(fn, reps=3):
-        best = float("inf")
-        for _ in range(reps):   # min of 3: the first call pays allocator / thread-pool warm-up
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                fn()
-            dt_ = time.perf_counter() - t0
-            spent[0] += dt_
-            best = min(best, dt_)
-        return best
-    t_io = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=0))
-    t_d = tm(lambda: pipe.model(x, t, cond, n_double=1, n_single=0)) - t_io
-    t_s = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=1)) - t_io
     lat = torch.randn(1, v["num_latents"], v["embed_dim"])
-    z = [None]
-    t_vae = tm(lambda: z.__setitem__(0, pipe.vae(lat)))
     img = torch.randn(1, 3, cfg["cond"]["image_size"], cfg["cond"]["image_size"])
-    t_cond = tm(lambda: pipe.conditioner.main_image_encoder.model(img))
     chunk = 16000  # reference num_chunks_hy, src/config.yaml:169
     pts = torch.from_numpy(H.dense_grid_points(1.01, R)[:chunk])[None]
-    t_chunk = tm(lambda: pipe.vae.geo_decoder(queries=pts, latents=z[0]))
+    n_chunks = -(-((R + 1) ** 3) // chunk)
+
     t0 = time.perf_counter()
     oracle_mesh = None
     try:
@@ -161,15 +145,40 @@ def cpu_baseline(cfg, steps, R, grid_np):
     except (ValueError, RuntimeError):
         pass
     t_mc = time.perf_counter() - t0
-    n_chunks = -(-((R + 1) ** 3) // chunk)
-    t_obj = (steps * (d["depth"] * t_d + d["depth_single_blocks"] * t_s + t_io) + v["num_decoder_layers"] * t_vae +
-             cfg["cond"]["num_hidden_layers"] * t_cond + n_chunks * t_chunk + t_mc)
-    measured = spent[0] + t_mc
-    return oracle_mesh, {"value": 1.0 / t_obj, "unit": "objects/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "extrapolated": True, "seconds_per_object": t_obj, "cpu_seconds_measured": measured,
-            "sample": "fp32 oracle at full widths: 1 double + 1 single DiT block (CFG batch 2, 4442 tokens), 1 VAE layer, "
-                      "1 DINOv2-g layer, 1 chunk of 16000 grid queries, C marching cubes on the full %d^3 grid; "
-                      "extrapolated x(%d steps x 16/32 blocks), x16 VAE, x40 DINO, x%d chunks" % (R + 1, steps, n_chunks)}
+
+    def sample(bf16, reps):
+        import contextlib
+        spent = [0.0]
+
+        def tm(fn):
+            best = float("inf")
+            for _ in range(reps):   # min of `reps`: the first call pays allocator / thread-pool warm-up
+                t1 = time.perf_counter()
+                with torch.no_grad(), (torch.autocast("cpu", dtype=torch.bfloat16) if bf16 else contextlib.nullcontext()):
+                    fn()
+                dt_ = time.perf_counter() - t1
+                spent[0] += dt_
+                best = min(best, dt_)
+            return best
+        t_io = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=0))
+        t_d = tm(lambda: pipe.model(x, t, cond, n_double=1, n_single=0)) - t_io
+        t_s = tm(lambda: pipe.model(x, t, cond, n_double=0, n_single=1)) - t_io
+        z = [None]
+        t_vae = tm(lambda: z.__setitem__(0, pipe.vae(lat)))
+        t_cond = tm(lambda: pipe.conditioner.main_image_encoder.model(img))
+        t_chunk = tm(lambda: pipe.vae.geo_decoder(queries=pts, latents=z[0]))
+        t_obj = (steps * (d["depth"] * t_d + d["depth_single_blocks"] * t_s + t_io) + v["num_decoder_layers"] * t_vae +
+                 cfg["cond"]["num_hidden_layers"] * t_cond + n_chunks * t_chunk + t_mc)
+        return t_obj, spent[0]
+    t_obj, spent32 = sample(False, 3)
+    t_obj16, spent16 = sample(True, 2)
+    what = ("1 double + 1 single DiT block (CFG batch 2, 4442 tokens), 1 VAE layer, 1 DINOv2-g layer, 1 chunk of 16000 grid queries, "
+            "C marching cubes on the full %d^3 grid; extrapolated x(%d steps x 16/32 blocks), x16 VAE, x40 DINO, x%d chunks" % (R + 1, steps, n_chunks))
+    return oracle_mesh, {"value": 1.0 / t_obj, "unit": "objects/sec", "cores": torch.get_num_threads(), "kind": "port", "dtype": "fp32",
+            "extrapolated": True, "seconds_per_object": t_obj, "cpu_seconds_measured": spent32 + t_mc,
+            "sample": "fp32 oracle at full widths: " + what,
+            "bf16": {"value": 1.0 / t_obj16, "unit": "objects/sec", "seconds_per_object": t_obj16, "cpu_seconds_measured": spent16,
+                     "how": "the same modules and sample under torch.autocast('cpu', dtype=torch.bfloat16); marching cubes as in fp32"}}
 
 
 def main():
@@ -214,10 +223,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # (round 6) a collective timeout and a watchdog: a dead or hung peer ends the job with a message that names it inside
+        # ~2 minutes instead of holding it until the launcher's limit (r3g/dist.py)
+        from r3g import dist as rdist0
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            rdist0.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            rdist0.init_process_group("nccl", rank=rank, world_size=world, device=torch.device("cuda", local))
 
     from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
     from r3g import ffi
@@ -249,7 +261,11 @@ def main():
         return pipe(image=list(imgs), num_inference_steps=S, octree_resolution=R, num_chunks=16000,
                     generator=[torch.Generator().manual_seed(1234567) for _ in imgs], output_type="raw")
 
-    def run(imgs, then=()):
+    wd = None
+    if dist is not None:
+        wd = rdist.Watchdog()           # (model load and the first launches are behind us: from here a rank reports progress)
+
+    def run(imgs, then=(), tag="run"):
         """launch group after launch group; while the GPU is in a group's denoising loop a host thread prepares the NEXT group's
         crops (recentre / resize / normalise, ~14 ms each: pipe.prefetch) -- `then` = the crops that follow `imgs`, so that a
         timed run prepares exactly as many crops inside its window as it processes (its own first group was prepared during
@@ -261,6 +277,8 @@ def main():
             if nxt and not a.no_prefetch:
                 pipe.prefetch(nxt)
             out_ += group(imgs[g0:g0 + B])
+            if wd is not None:
+                wd.beat("%s: launch group %d of %d done" % (tag, g0 // B + 1, -(-len(imgs) // B)))
         return out_
 
     def barrier():
@@ -268,7 +286,7 @@ def main():
             rdist.barrier()
         torch.cuda.synchronize()
 
-    run(crops[:a.warmup], then=crops[a.warmup:a.warmup + B])
+    run(crops[:a.warmup], then=crops[a.warmup:a.warmup + B], tag="warm-up")
     if dist is not None:
         # the mesh return's point-to-point channels (RCCL opens one per pair of ranks on first use) are opened by a one-vertex
         # gather before the clock starts, like every other first-use cost of the warm-up
@@ -276,22 +294,36 @@ def main():
                             to_host=False)
     barrier()
     t0 = time.perf_counter()
-    meshes = run(crops[a.warmup:a.warmup + a.steps], then=crops[a.warmup + a.steps:a.warmup + a.steps + B])   # EXACTLY a.steps objects
+    meshes = run(crops[a.warmup:a.warmup + a.steps], then=crops[a.warmup + a.steps:a.warmup + a.steps + B], tag="weak")   # EXACTLY a.steps objects
     last = meshes[-1] if meshes else None
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0
+    t_gather = 0.0
     if dist is not None:       # the meshes travel to rank 0 over RCCL (point-to-point, variable length)
+        tg = time.perf_counter()
         made = [(rank + world * (a.warmup + j), m[0], m[1]) for j, m in enumerate(meshes) if m is not None]
         gathered = rdist.gather_meshes(made, dst=0, to_host=False)     # the raw meshes stay in rank 0's HBM
         if rank == 0 and len(gathered) != world * a.steps:
             raise SystemExit("gather_meshes returned %d of %d meshes" % (len(gathered), world * a.steps))
         del gathered, made
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg
+        wd.beat("weak: meshes gathered")
+    tb = time.perf_counter()
     barrier()
+    t_wait = time.perf_counter() - tb
     dt = time.perf_counter() - t0
     last_grid = pipe.last_grid
+    per_rank_weak = None
     if dist is not None:
         tt = torch.tensor([dt], device=rdist._comm_device(), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # one record per rank (round 6): were < N x the objects per second load balance (compute_s spread), the mesh return
+        # (gather_s) or host contention (compute_s uniformly above the one-GPU figure)?  gather_s of a rank that finished early
+        # includes its wait for rank 0 to reach the gather; end_wait_s is the closing barrier.
+        per_rank_weak = rdist.exchange_json({"rank": rank, "objects": len(meshes), "compute_s": round(t_compute, 4), "queue_wait_s": 0.0,
+                                             "gather_s": round(t_gather, 4), "end_wait_s": round(t_wait, 4)}, name="bench_weak_ranks", dst=0)
 
     strong = None
     if dist is not None:
@@ -302,21 +334,36 @@ def main():
         barrier()
         t1 = time.perf_counter()
         mine = []
+        s_claim = s_compute = 0.0
         while True:
+            tc = time.perf_counter()
             idx = q.claim_many(B)
+            s_claim += time.perf_counter() - tc
             if not idx:
                 break
+            tc = time.perf_counter()
             ms_ = group([Image.fromarray(dev_crops[i % len(dev_crops)].cpu().numpy(), "RGBA") for i in idx])
+            torch.cuda.synchronize()
+            s_compute += time.perf_counter() - tc
             mine += [(i, m[0], m[1]) for i, m in zip(idx, ms_) if m is not None]
+            wd.beat("strong: %d objects done" % len(mine))
+        tg = time.perf_counter()
         got = rdist.gather_meshes(mine, dst=0, to_host=False)
         torch.cuda.synchronize()
+        s_gather = time.perf_counter() - tg
+        wd.beat("strong: meshes gathered")
+        tb = time.perf_counter()
         barrier()
+        s_wait = time.perf_counter() - tb
         ts = torch.tensor([time.perf_counter() - t1], device=rdist._comm_device(), dtype=torch.float64)
         dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        per_rank_strong = rdist.exchange_json({"rank": rank, "objects": len(mine), "compute_s": round(s_compute, 4),
+                                               "queue_wait_s": round(s_claim, 4), "gather_s": round(s_gather, 4),
+                                               "end_wait_s": round(s_wait, 4)}, name="bench_strong_ranks", dst=0)
         if rank == 0:
             assert len(got) == total_s
             strong = {"objects_total": total_s, "seconds": float(ts.item()), "value": total_s / float(ts.item()),
-                      "unit": "objects/sec", "assignment": "dynamic queue, %d per claim" % B}
+                      "unit": "objects/sec", "assignment": "dynamic queue, %d per claim" % B, "per_rank": per_rank_strong}
         del got, mine
 
     out = None
@@ -337,8 +384,14 @@ def main():
         # upstream's algorithmic FLOPs over the measured time.  The kernels EXECUTE about 9 % fewer FLOPs
         # (CFG de-duplication), so the hardware's own utilisation is lower than this figure: see "..._executed" below.
         out["mfma_utilisation_end_to_end"] = out["flops_per_object"] * out["value"] / world / (PEAK_BF16_TFLOPS * 1e12)
+        if per_rank_weak is not None:
+            out["per_rank"] = per_rank_weak
         if strong is not None:
             out["strong"] = strong
+        # launch groups whose fp16 residual stream overflowed and that ran again on the fp32 stream (twice their time), of all
+        # launch groups this process ran (r3g_get_counter)
+        out["dit_f16_fallbacks"] = ffi.counter("dit_f16_fallbacks")
+        out["dit_groups"] = ffi.counter("dit_groups")
 
     if rank == 0 and not a.no_roofline:
         L = ffi.lib()
@@ -448,6 +501,7 @@ def main():
     if bad:
         raise SystemExit("bench.py: the timed object's mesh differs from the marching-cubes oracle's mesh of the same grid")
     if dist is not None:
+        wd.done()
         rdist.barrier()
         dist.destroy_process_group()
 

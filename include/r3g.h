@@ -423,11 +423,10 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * phases, work and barrier wait, per launch to stderr -- timing experiments, synchronous), "dit_f16_guard" (1 default: the final latents of a launch group that ran
  * on the fp16 stream are checked for NaN / infinity and a group that overflowed runs again on the fp32 stream, with a line on
  * stderr | 0: no check),
- * "attn_variant" (round 6; generations 2 / 6 / 7: bit 0 -- default on -- the FAST pass takes no maximum after the first key block and
- * tests the sum of a lane's 16 exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its query
- * tile again with variant 0's body; bit 1 -- the row sum on plain v_add_f32 instead of the packed adder, same order; 0 = rounds
- * 2-5.  Bit-identical to variant 0 unless variant 0 would have moved its stabiliser where the fast pass does not: then equal
- * within the bf16 rounding of P),
+ * "attn_variant" (round 6; generations 2 / 6 / 7: 1 default -- the FAST pass takes no maximum after the first key block and tests
+ * the sum of a lane's 16 exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its query tile
+ * again with variant 0's body | 0 = rounds 2-5.  Bit-identical to variant 0 unless variant 0 would have moved its stabiliser where
+ * the fast pass does not: then equal within the bf16 rounding of P),
  * "gemm_epi_slices" (1 default, round 6 | 0: the persistent phased kernel's bf16 / fused-QKV epilogues in 32-row passes through 4 KiB of
  * extra scratch per wave instead of 64-row passes through the wave's own staging slices of the idle k-tile buffer), "gemm_mixed" (1
  * default, round 6 | 0: a DiT single block's fused QKV projection and MLP-in + GELU projection as two launches instead of one
@@ -438,6 +437,12 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation
  * (different rounding points inside the softmax). */
 int r3g_set_option(const char* name, int value);
+/* Process-wide event counters (round 6).  "dit_f16_fallbacks": launch groups of r3g_flow_sample_batch whose fp16 residual stream
+ * produced non-finite latents and that therefore ran a second time on the fp32 stream ("dit_f16_guard"; such a group costs twice its
+ * time -- bench.py and the stage report carry the count so that a slow run says why).  "dit_groups": launch groups run so far.
+ * r3g_flow_sample_batch is SYNCHRONOUS while the guard is on (one 4-byte read-back per group) and must not be captured into a
+ * hipGraph then; with "dit_f16_guard" 0 or "dit_resid_f16" 0 it only enqueues work.  Unknown name: R3G_ERR_INVALID. */
+int r3g_get_counter(const char* name, int64_t* value);
 /* operand staging of the MFMA kernels: 1 = LDS-DMA (global_load_lds, default), 0 = through registers */
 int r3g_set_staging(int use_lds_dma);
 

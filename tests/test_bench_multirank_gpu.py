@@ -40,3 +40,13 @@ def test_bench_with_eight_ranks_on_one_device(world):
     assert out["config"]["objects_total"] == world * 4 and out["value"] > 0
     # the strong block: 8 crops per rank through the shared queue, every mesh came back to rank 0
     assert out["strong"]["objects_total"] == 8 * world and out["strong"]["value"] > 0
+    # round 6: one record per rank in both blocks -- which of load balance, mesh return and host contention a scaling number below
+    # N x is made of -- and the fp16-guard counter
+    for block, objects in ((out["per_rank"], world * 4), (out["strong"]["per_rank"], 8 * world)):
+        assert [r["rank"] for r in block] == list(range(world))
+        assert sum(r["objects"] for r in block) == objects
+        for r in block:
+            assert set(r) >= {"objects", "compute_s", "queue_wait_s", "gather_s", "end_wait_s"}
+            assert r["compute_s"] >= 0 and r["gather_s"] >= 0 and r["queue_wait_s"] >= 0
+    assert all(r["objects"] == 4 for r in out["per_rank"])
+    assert out["dit_f16_fallbacks"] == 0 and out["dit_groups"] > 0

@@ -25,8 +25,8 @@ newtests)
     cat $O/r06_newtests.txt
     ;;
 attn)
-    timeout 400 python tools/bench_attn.py --gens "${2:-2v0,2v1,2v2,2v3}" --shapes 0,2,3 --rounds 4 --iters 5 > $O/r06_attn_gen2.jsonl 2> $O/r06_attn_gen2.err
-    timeout 400 python tools/bench_attn.py --gens "${3:-6v0,6v1,6v2,6v3}" --shapes 1 --rounds 4 --iters 5 > $O/r06_attn_gen6.jsonl 2> $O/r06_attn_gen6.err
+    timeout 400 python tools/bench_attn.py --gens "${2:-2v0,2v1}" --shapes 0,2,3 --rounds 4 --iters 5 > $O/r06_attn_gen2.jsonl 2> $O/r06_attn_gen2.err
+    timeout 400 python tools/bench_attn.py --gens "${3:-6v0,6v1}" --shapes 1 --rounds 4 --iters 5 > $O/r06_attn_gen6.jsonl 2> $O/r06_attn_gen6.err
     python - <<PY
 import json
 for f in ("$O/r06_attn_gen2.jsonl", "$O/r06_attn_gen6.jsonl"):
