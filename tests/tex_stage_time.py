@@ -62,6 +62,32 @@ def main():
     timed("delight_only_ms", lambda: delight(image))
     nm = [Image.new("RGB", (512, 512), (128, 128, 255))] * 6
     timed("multiview_only_ms", lambda: net(image.convert("RGB"), nm + nm, [21, 12, 15, 18, 43, 37]))
+    # round 6: the same two flows once more with every launch bracketed by HIP events (r3g_prof_*): algorithmic
+    # FLOPs and achieved TFLOP/s of the MFMA families (every convolution / linear layer is a GEMM launch, attention is the flash
+    # kernel), milliseconds of the rest
+    import ctypes
+    from r3g import ffi
+    L = ffi.lib()
+    fams = ["gemm", "attention", "layernorm", "qkv_split", "gemv", "elementwise", "mc_classify", "mc_other", "mesh"]
+    roof = {}
+    for name, fn in (("delight", lambda: delight(image)), ("multiview", lambda: net(image.convert("RGB"), nm + nm, [21, 12, 15, 18, 43, 37]))):
+        torch.cuda.synchronize()
+        ffi.check(L.r3g_prof_enable(1))
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        wall = 1000.0 * (time.perf_counter() - t)
+        n = len(fams)
+        cnt, ms, work = (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        ffi.check(L.r3g_prof_read(cnt, ms, work, n))
+        ffi.check(L.r3g_prof_enable(0))
+        roof[name] = {"wall_ms_with_events": round(wall, 1),
+                      "families": {fams[i]: {"launches": int(cnt[i]), "ms": round(float(ms[i]), 2),
+                                             **({"tflop": round(float(work[i]) / 1e12, 3),
+                                                 "tflops_achieved": round(float(work[i]) / max(float(ms[i]), 1e-9) / 1e9, 1),
+                                                 "frac_of_2500": round(float(work[i]) / max(float(ms[i]), 1e-9) / 1e9 / 2500.0, 3)} if fams[i] in ("gemm", "attention") else {})}
+                                   for i in range(n) if cnt[i]}}
+    times["roofline"] = roof
     print(json.dumps({"what": "texture stage at upstream's sizes, both diffusion models on the HIP blocks, random weights",
                       "faces": int(len(f)), "texture": list(out.texture.shape), "delight_steps": delight.steps, "multiview_steps": net.steps,
                       "views": 6, "view_size": net.view_size, "guidance_scale": 2.0, "setup_seconds_cpu_weight_synthesis": round(setup, 1),

@@ -8,7 +8,10 @@ reference path calls: skimage.measure.marching_cubes(grid, level,
 method="lewiner") (upstream hy3dgen surface_extractors.MCSurfaceExtractor.run,
 reached from reference src/2d_to_3d_models/run.py:77-84).
 
-    python tools/make_mc_golden.py
+    python tools/make_mc_golden.py                  # (re)write tests/golden/mc_*
+    python tools/make_mc_golden.py --check          # regenerate into a scratch directory and DIFF against the committed fixtures
+    R3G_SKIMAGE_PYTHON=/path/to/python ...          # another interpreter with another scikit-image (oracle/README.md: the reference
+                                                    # asks for >= 0.24.0, the container has 0.18.3): --check then says whether the pin moved
 """
 import hashlib
 import json
@@ -24,7 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mc_volumes import golden_volume, small_volumes, cube_zoo  # noqa: E402
 
-CONDA_PY = "/opt/conda/bin/python3.9"
+CONDA_PY = os.environ.get("R3G_SKIMAGE_PYTHON", "/opt/conda/bin/python3.9")
 BATCH = r"""
 import sys, warnings
 warnings.filterwarnings("ignore")
@@ -55,8 +58,31 @@ def run_skimage(vols, method="lewiner"):
         return {k: r[k] for k in r.files}
 
 
-def main():
-    gold = os.path.join(ROOT, "tests", "golden")
+def check():
+    """regenerate with the interpreter at hand and compare with tests/golden/ (arrays bit for bit, the sha table entry by entry)"""
+    committed = os.path.join(ROOT, "tests", "golden")
+    with tempfile.TemporaryDirectory() as scratch:
+        main(scratch)
+        bad = []
+        old, new = (json.load(open(os.path.join(d, "mc_sha.json"))) for d in (committed, scratch))
+        print("committed fixtures: scikit-image %s; this interpreter: %s" % (old["_meta"]["skimage"], new["_meta"]["skimage"]))
+        for k in sorted(set(old) | set(new)):
+            if k != "_meta" and old.get(k) != new.get(k):
+                bad.append("mc_sha.json[%s]" % k)
+        for name in ("mc_small.npz", "mc_cubes.npz"):
+            a, b = np.load(os.path.join(committed, name)), np.load(os.path.join(scratch, name))
+            for k in sorted(set(a.files) | set(b.files)):
+                if k not in a.files or k not in b.files or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
+                    bad.append("%s[%s]" % (name, k))
+    if bad:
+        print("THE PIN MOVED: %d entries differ, e.g. %s" % (len(bad), bad[:8]))
+        return 1
+    print("identical: every fixture reproduces bit for bit")
+    return 0
+
+
+def main(gold=None):
+    gold = gold or os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     # 1. SURVEY.md 4.3 vectors A-D (hashes only: D alone is 6.8 MB of output)
     vols = {}
@@ -108,4 +134,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(check() if "--check" in sys.argv[1:] else main())

@@ -81,6 +81,16 @@ cfg4)
     timeout 900 python bench.py --gpus 1 --octree-resolution 512 --fp8-geo --steps 4 --warmup 4 --no-cpu-baseline > $O/r06_bench_cfg4.json 2> $O/r06_bench_cfg4.err
     cut -c1-1200 $O/r06_bench_cfg4.json; tail -3 $O/r06_bench_cfg4.err
     ;;
+texprof)
+    # where the texture step's time goes at upstream's sizes: kernel trace of tests/tex_stage_time.py, by kernel and by (kernel, grid)
+    R=$(pwd)
+    (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/r06_tex_trace -o t -- python $R/tests/tex_stage_time.py > $R/$O/r06_texture_stage_time_traced.json 2> $R/$O/r06_tex_trace.log)
+    DB=$(ls $O/r06_tex_trace/*/*_results.db $O/r06_tex_trace/*_results.db 2>/dev/null | head -1)
+    python tools/rocprof_summary.py $DB "texture step (tests/tex_stage_time.py: warm-up + whole + delight + six views + the two event-timed passes)" > $O/r06_tex_kernel_stats.md
+    python tools/rocprof_summary.py $DB "texture step, by (kernel, grid)" --by-grid > $O/r06_tex_kernel_stats_by_grid.md
+    head -30 $O/r06_tex_kernel_stats.md | cut -c1-200
+    rm -rf $O/r06_tex_trace
+    ;;
 evidence)
     bash tools/profile_evidence.sh "$2" "${3:-4}" r06
     ;;
