@@ -714,6 +714,60 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
             else hipLaunchKernelGGL((ln_dot_kernel<XB, 0, 1>), g1, blk, 0, s, x, ldx, rows, C, do_ln, lnw, lnb, eps, w, b, out);    \
         }                                                                                                                  \
     }
+// ---- round 6: ln_post + output_proj folded into the last residual GEMM of the geo decoder (EPI_RESID_BF16_LND, kernels.h) -------------
+// gw[n] = lnw[n] * w[n];  consts[0] = sum gw,  consts[1] = sum lnb[n] * w[n] + b   (one workgroup, fixed summation order)
+__global__ __launch_bounds__(256) void lnd_prepare_kernel(const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                          const float* __restrict__ w, float b, int N, float* __restrict__ gw,
+                                                          float* __restrict__ consts) {
+    __shared__ double sg[256], sb[256];
+    double ag = 0.0, ab = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float g = (lnw ? lnw[n] : 1.0f) * w[n];
+        gw[n] = g;
+        ag += (double)g;
+        ab += (double)(lnb ? lnb[n] : 0.0f) * (double)w[n];
+    }
+    sg[threadIdx.x] = ag;
+    sb[threadIdx.x] = ab;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { sg[threadIdx.x] += sg[threadIdx.x + st]; sb[threadIdx.x] += sb[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { consts[0] = (float)sg[0]; consts[1] = (float)(sb[0] + (double)b); }
+}
+
+// part [rows][parts][4] = {sum, sum of squared deviations from the chunk mean, sum x gw, -} of 64-column chunks -> out[row]:
+// mean = sum S / N;  M2 = sum m2_i + 64 sum (S_i / 64 - mean)^2  (Chan et al.: exact merge of per-chunk moments);
+// logit = rsqrt(M2 / N + eps) * (dot - mean * consts[0]) + consts[1].  One thread per row, chunks in ascending order.
+__global__ __launch_bounds__(256) void lnd_finalize_kernel(const float4* __restrict__ part, int rows, int parts, float eps,
+                                                           const float* __restrict__ consts, float* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float4* p = part + (int64_t)r * parts;
+    float S = 0.f, D = 0.f;
+    for (int i = 0; i < parts; ++i) { S += p[i].x; D += p[i].z; }
+    const float N = 64.0f * (float)parts;
+    const float mean = S / N;
+    float M2 = 0.f;
+    for (int i = 0; i < parts; ++i) {
+        const float dm = p[i].x * (1.0f / 64.0f) - mean;
+        M2 += p[i].y + 64.0f * dm * dm;
+    }
+    out[r] = rsqrtf(M2 / N + eps) * (D - mean * consts[0]) + consts[1];
+}
+
+hipError_t lnd_prepare_launch(const float* lnw, const float* lnb, const float* w, float b, int N, float* gw, float* consts, hipStream_t s) {
+    hipLaunchKernelGGL(lnd_prepare_kernel, dim3(1), dim3(256), 0, s, lnw, lnb, w, b, N, gw, consts);
+    return hipGetLastError();
+}
+
+hipError_t lnd_finalize_launch(const float* part, int rows, int parts, float eps, const float* consts, float* out, hipStream_t s) {
+    ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);
+    hipLaunchKernelGGL(lnd_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const float4*)part, rows, parts, eps, consts, out);
+    return hipGetLastError();
+}
+
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb,
                          float eps, const float* w, float b, float* out, hipStream_t s, int x_bf16) {
     ProfScope prof_scope_(PC_ELEMWISE, 0.0, s);

@@ -373,8 +373,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         }
         return;
     }
-    if constexpr (EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16) {
+    if constexpr (EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16 || EPI == EPI_RESID_BF16_LND) {
         constexpr bool F16 = EPI == EPI_RESID_F16;
+        constexpr bool LND = EPI == EPI_RESID_BF16_LND;   // the new values are not stored: per-row chunk statistics instead (kernels.h)
         // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
         uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
         const uint16_t* XR = p.resid_src ? p.resid_src + (int64_t)batch * p.strideC : X;   // where the old values come from
@@ -398,6 +399,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             constexpr int GP = PI / 2;          // 16-row groups per pass
             const int cc = lane & 7;
             const int n = n0 + wc * 64 + cc * 8;
+            f32x4 gw0 = (f32x4){0.f, 0.f, 0.f, 0.f}, gw1 = gw0;
+            if constexpr (LND) {
+                const int nc = n < p.N ? n : p.N - 8;
+                gw0 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc);
+                gw1 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc + 4);
+            }
 #pragma unroll
             for (int ip = 0; ip < MI; ip += GP) {
                 uint4 old[RP / 8];
@@ -432,13 +439,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         const f32x4& d = k < 2 ? d0 : d1;
                         q[k] = pack16<F16>(ov[0] + d[(k & 1) * 2], ov[1] + d[(k & 1) * 2 + 1]);
                     }
-                    if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
+                    if constexpr (LND) {
+                        // the row's 64 columns of this wave sit in the 8 lanes that share lane >> 3: chunk sum, then the squared
+                        // deviations from the chunk mean and the dot product with gamma * w, each reduced over those lanes
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x2 u = unpack16<false>(q[k]);
+                            v[2 * k] = u[0];
+                            v[2 * k + 1] = u[1];
+                        }
+                        float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                        s1 += __shfl_xor(s1, 1, 64);
+                        s1 += __shfl_xor(s1, 2, 64);
+                        s1 += __shfl_xor(s1, 4, 64);
+                        const float mu = s1 * (1.0f / 64.0f);
+                        float m2 = 0.f, s3 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float dv = v[k] - mu;
+                            m2 = fmaf(dv, dv, m2);
+                            s3 = fmaf(v[k], k < 4 ? gw0[k] : gw1[k - 4], s3);
+                        }
+                        m2 += __shfl_xor(m2, 1, 64); s3 += __shfl_xor(s3, 1, 64);
+                        m2 += __shfl_xor(m2, 2, 64); s3 += __shfl_xor(s3, 2, 64);
+                        m2 += __shfl_xor(m2, 4, 64); s3 += __shfl_xor(s3, 4, 64);
+                        if (cc == 0 && m < p.M && n < p.N)
+                            *reinterpret_cast<f32x4*>(p.lnd_part + ((int64_t)m * (p.N >> 6) + ((n0 >> 6) + wc)) * 4) = (f32x4){s1, m2, s3, 0.f};
+                    } else {
+                        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
             return;
         }
+        if constexpr (LND) return;   // (the launcher only admits launches that take the wide path)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint2 old[MI];
@@ -1771,7 +1808,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
 }
 
 bool g_gemm_xcd_walk = true;   // persistent kernel: an XCD walks one contiguous range of the tile order (round 5) | 0: rounds 2-4's walk
-bool g_gemm_persistent_qkv = false;  // fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel (measured: +17 ms per object, off)
+bool g_gemm_persistent_qkv = true;   // fused QKV launches with more 256x256 tiles than CUs (the double blocks' img + txt pair) on the persistent phased kernel: round 4's 32-row passes cost +17 ms per object, round 6's 64-row passes through the idle k-tile buffer -4 ms (profiles/r06_ab.md)
 bool g_gemm_epi_slices = true;   // persistent kernel, bf16 / fused-QKV epilogues: 64-row passes through the wave's slices of k-tile buffer 1 (round 6) | 0: 32-row passes
 bool g_gemm_mixed = true;        // a single block's [fused QKV | MLP-in + GELU] as ONE persistent launch (round 6) | 0: two launches
 
@@ -2115,7 +2152,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
     // algorithmic bytes of a launch: each operand read once, the result written once (fp32 residual: read + written)
     auto alg_bytes = [](const GemmArgs& g) {
         if (g.M <= 0) return 0.0;
-        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 || g.epi == EPI_RESID_F16 ? 4.0 : (g.epi == EPI_FP8_GELU_ERF ? 1.0 : 2.0));
+        const double out = g.epi == EPI_RESID_F32 ? 8.0 : (g.epi == EPI_F32 || g.epi == EPI_RESID_BF16 || g.epi == EPI_RESID_F16 ? 4.0 : g.epi == EPI_RESID_BF16_LND ? 2.0 : (g.epi == EPI_FP8_GELU_ERF ? 1.0 : 2.0));
         return (double)g.batch * (2.0 * g.M * g.K + out * (double)g.M * g.N) + 2.0 * (double)g.N * g.K;
     };
     ProfScope ps(PC_GEMM, 2.0 * (double)p.M * p.N * p.K * batch + 2.0 * (double)p2.M * p2.N * p2.K * p2.batch, s,
@@ -2186,6 +2223,16 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
                                    p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
             return hipGetLastError();
         }
+    }
+    if (p.epi == EPI_RESID_BF16_LND) {
+        // one problem on the phased 256 x 256 kernel, wide read-modify-write epilogue (its alignment rules checked here: the
+        // epilogue has no other path for this form)
+        const uint16_t* xr = p.resid_src ? p.resid_src : reinterpret_cast<const uint16_t*>(p.C);
+        if (p2.M > 0 || batch != 1 || !g_gemm_glds || !p.wide_epilogue || !p.lnd_gw || !p.lnd_part || p.gate || p.K % 128 || p.K < 256 ||
+            p.N % 256 || (p.ldc & 7) || (reinterpret_cast<uintptr_t>(p.C) & 15) || (reinterpret_cast<uintptr_t>(xr) & 15) ||
+            (reinterpret_cast<uintptr_t>(p.lnd_gw) & 15) || (reinterpret_cast<uintptr_t>(p.lnd_part) & 15))
+            return hipErrorInvalidValue;
+        return launch_gemm8<EPI_RESID_BF16_LND>(p, p2, s);
     }
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, p2, g_gemm_glds, s);

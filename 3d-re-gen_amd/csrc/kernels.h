@@ -17,6 +17,11 @@ enum GemmEpilogue {
     EPI_RESID_BF16 = 6,      // C(bf16) = bf16(C + gate[b][n] * (acc + bias)): a 16-bit residual stream (sum formed in fp32)
     EPI_FP8_GELU_ERF = 7,    // C(e4m3) = fp8(gelu_erf(acc + bias) * out_inv_scale): operand of a following fp8 GEMM (static scale)
     EPI_RESID_F16 = 8,       // C(fp16) = fp16(C + gate[b][n] * (acc + bias)): the reference's own stream type (its pipelines run in fp16)
+    // Round 6: the LAST residual GEMM of the geo decoder with ln_post + output_proj folded in.  x = bf16(C + acc + bias) is formed as in
+    // EPI_RESID_BF16 but NOT stored: every wave writes, per row, the statistics of its 64 columns -- {sum, sum of squared deviations
+    // from the chunk mean, sum of x * lnd_gw[n]} -- to lnd_part[row][N / 64][4]; lnd_finalize_launch merges the chunks (Chan's
+    // formula, fixed order) into logit = rstd * (dot - mean * sum(gw)) + const.  One problem, 256 x 256 phased kernel only.
+    EPI_RESID_BF16_LND = 9,
 };
 
 enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
@@ -91,6 +96,8 @@ struct GemmArgs {
     float* split_ws;
     int64_t split_ws_elems;
     ConvA conv;         // conv.x != null: A is the implicit im2col matrix of conv.x (fp32 epilogues, one problem, 128x128 kernel)
+    const float* lnd_gw;   // EPI_RESID_BF16_LND: ln_post.weight[n] * output_proj.weight[n], f32 [N]
+    float* lnd_part;       // EPI_RESID_BF16_LND: f32 [M][N / 64][4]
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
@@ -104,7 +111,7 @@ void attn_set_pipelined(bool on);  // software-pipelined attention kernel (off b
 void gemm_set_config(int waves);   // tile kernel: 0 automatic | 4 | 8 | 9 | 10 | 11 | 12 | 13 | 16 | 32 (include/r3g.h)
 void gemm_set_raster(int group);
 void gemm_set_auto_rule(int rule, int num_cu);  // tile-choice rule (0: first version, 1: current); num_cu > 0 sets the CU count
-void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default off: measured slower)
+void gemm_set_persistent_qkv(bool on);   // fused QKV launches on the persistent phased kernel (default on since round 6)
 void gemm_set_epi_slices(bool on);   // persistent phased kernel: bf16 / fused-QKV epilogues in 64-row passes through the wave's slices of k-tile buffer 1 (default on)
 void gemm_set_mixed(bool on);        // a single block's [fused QKV | MLP-in + GELU] as one persistent launch (default on)
 // fused QKV projection (pq, EPI_QKV) and MLP-in + GELU(tanh) (pm) over the same rows: one launch when the grid fills the machine
@@ -225,6 +232,10 @@ hipError_t swiglu_launch(const uint16_t* in, int64_t ldi, uint16_t* out, int64_t
 hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, double bound, int num_freqs,
                                int include_pi, hipStream_t s);
 // logits[r] = LN(x[r]) . w + b  (ln_post + output_proj fused);  x f32 [rows][C]
+// EPI_RESID_BF16_LND's two small kernels (elem.hip): gw[n] = lnw[n] * w[n], consts = {sum gw, sum lnb[n] w[n] + b}; and the merge of the
+// per-chunk statistics into out[row] = rstd * (dot - mean * consts[0]) + consts[1]
+hipError_t lnd_prepare_launch(const float* lnw, const float* lnb, const float* w, float b, int N, float* gw, float* consts, hipStream_t s);
+hipError_t lnd_finalize_launch(const float* part, int rows, int parts, float eps, const float* consts, float* out, hipStream_t s);
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb, float eps,
                          const float* w, float b, float* out, hipStream_t s, int x_bf16 = 0);
 // DINOv2 patch embedding im2col: image f32 [3][S][S] -> bf16 [P*P][Kpad], K = 3*ps*ps ordered (c, dy, dx)

@@ -61,6 +61,7 @@ static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached 
 static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_dit_f16_guard = true;    // option "dit_f16_guard": check the latents of an fp16-stream group, fall back to fp32 on overflow
+static bool g_geo_lnd_fused = true;   // option "geo_lnd_fused" (round 6): ln_post + output_proj folded into the geo decoder's last residual GEMM
 static int64_t g_dit_groups = 0;         // launch groups r3g_flow_sample_batch has run (r3g_get_counter)
 static int g_dit_f16_fallbacks = 0;    // how often that happened (r3g_set_option("dit_f16_fallbacks_reset", ...) / stderr line)
 static bool g_dit_resid_f16 = true;   // the DiT's residual stream of the de-duplicated CFG path in fp16 (the reference's activation type) instead of fp32
@@ -106,6 +107,7 @@ struct Model {
     struct W8 { uint8_t* w8; float* sw; };
     std::unordered_map<const void*, W8> w8;
     float *fp8_sa = nullptr, *fp8_sconst = nullptr;
+    float *lnd_gw = nullptr, *lnd_part = nullptr;   // EPI_RESID_BF16_LND: gamma * w [W] + 2 constants, chunk statistics [qc][W / 64][4]
     // activation arena of the CFG-de-duplicated DiT for `cap` objects per launch (allocated on first use), and the segment
     // tables of its fused QKV epilogues for `nb` objects
     struct DitBatch {
@@ -862,6 +864,16 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         std::fill(gq.built.begin(), gq.built.end(), 0);
         gq.epoch = g_option_epoch;
     }
+    // Round 6: ln_post + output_proj inside the last residual GEMM (EPI_RESID_BF16_LND): the final stream x2 is never written or
+    // read again (2 x 268 MB per pass) and the ln_dot launch becomes a 33 MB merge of per-chunk statistics.  bf16 stream, bf16 MLP.
+    const bool lnd = g_geo_lnd_fused && xb && !f8m && c.vae_ln_post && W % 256 == 0 && W <= 4096 && lfc.N % 128 == 0 && lfc.N >= 256;
+    if (lnd) {
+        if (!m.lnd_gw) {
+            R3G_TRY(hipMalloc((void**)&m.lnd_gw, 4 * (size_t)(W + 64)));
+            R3G_TRY(hipMalloc((void**)&m.lnd_part, 16 * (size_t)m.qc * (size_t)(W / 64)));
+        }
+        R3G_TRY(lnd_prepare_launch(lpw, lpb, ow, ob, W, m.lnd_gw, m.lnd_gw + W, s));      // (per call: the weights may have been re-registered)
+    }
     for (int64_t off = 0; off < count; off += m.qc) {
         const int n = (int)std::min<int64_t>(m.qc, count - off);
         const int npad = (int)rup(n, 128);
@@ -914,6 +926,15 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         } else {
             R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
             R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+            if (lnd) {
+                GemmArgs pl = gemm_args(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, EPI_RESID_BF16_LND, nullptr, 0);
+                pl.lnd_gw = m.lnd_gw;
+                pl.lnd_part = m.lnd_part;
+                hipError_t e = gemm_launch(pl, 1, s);
+                if (e != hipSuccess) return hip_fail(e, "gemm_launch(geo mlp.c_proj + ln_post + output_proj)");
+                R3G_TRY(lnd_finalize_launch(m.lnd_part, n, W / 64, 1e-5f, m.lnd_gw + W, grid + start + off, s));
+                continue;
+            }
             R3G_RC(gemm(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, epi_res, nullptr, 0, 1, s));
         }
         R3G_TRY(ln_dot_launch(m.f32a, W, n, W, c.vae_ln_post, lpw, lpb, 1e-5f, ow, ob, grid + start + off, s, xb));
@@ -984,6 +1005,8 @@ static void model_free(Model* m) {
         (void)hipFree(kv.second.sw);
     }
     if (m->fp8_sa) (void)hipFree(m->fp8_sa);
+    if (m->lnd_gw) (void)hipFree(m->lnd_gw);
+    if (m->lnd_part) (void)hipFree(m->lnd_part);
     if (m->fp8_sconst) (void)hipFree(m->fp8_sconst);
     if (m->db.base) (void)hipFree(m->db.base);
     if (m->gq.x0) (void)hipFree(m->gq.x0);
@@ -1351,6 +1374,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_splitk128")) gemm_set_splitk128(value != 0);
     else if (!strcmp(name, "conv_implicit")) gemm_set_conv_implicit(value != 0);
     else if (!strcmp(name, "gemm_xcd_walk")) gemm_set_xcd_walk(value != 0);
+    else if (!strcmp(name, "geo_lnd_fused")) g_geo_lnd_fused = value != 0;
     else if (!strcmp(name, "attn_variant")) attn_set_variant(value);
     else if (!strcmp(name, "gemm_epi_slices")) gemm_set_epi_slices(value != 0);
     else if (!strcmp(name, "gemm_mixed")) gemm_set_mixed(value != 0);

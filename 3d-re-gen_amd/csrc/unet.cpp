@@ -314,7 +314,7 @@ static int unet_transformer(Unet& u, const std::string& pre, float* x, int H, in
     U_RC(u_lin(u, blk + ".ff.net.0.proj", true, 8 * C, C, &f0));
     U_RC(u_lin(u, blk + ".ff.net.2", true, C, 4 * C, &f2));
     // (per GROUP: a guidance pair of ONE view is two groups of one sample each -- the two-call form runs no multiview attention
-    // on a single view, oracle/unet2p5d_torch.py `n > 1`, and the pair must equal it)
+    // on a single view (upstream's block: `n > 1`), and the pair must equal it)
     const bool has_mv = nb / G > 1 && u.w.count(blk + ".attn_multiview.to_qkv.weight");
     const auto cond_it = u.w.find("cond:" + pre);
     const bool has_ref = (u.mv_flags & 2) && cond_it != u.w.end() && u.w.count(blk + ".attn_refview.to_q.weight");

@@ -181,25 +181,26 @@ class Hunyuan3DDiTPipeline:
         return lock
 
     def prefetch(self, images):
-        """start the host-side preparation of `images` (a coming call's objects) on a background thread; the call that is
-        made with these same image objects picks the results up.  Up to _PREFETCH_MAX_GROUPS groups may be pending."""
+        """start the host-side preparation of `images` (a coming call's objects) on a background thread; a later call made with
+        any of these image OBJECTS picks their results up.  Round 6: kept per image (identity), not per group -- a caller whose
+        groups are cut differently from its prefetches (bench.py: a warm-up of 5 crops in groups of 4) still gets every crop
+        prepared once, on the worker.  At most _PREFETCH_MAX_GROUPS x 8 images pending; the oldest nobody came for go first."""
+        import collections
         import concurrent.futures
         if getattr(self, "_prefetch_pool", None) is None:
             self._prefetch_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="r3g-host-prep")
-            self._prefetched = {}
+            self._prefetched = collections.OrderedDict()
         images = list(images) if isinstance(images, (list, tuple)) else [images]
-        key = tuple(id(im) for im in images)
-        if key in self._prefetched:
-            return
-        while len(self._prefetched) >= self._PREFETCH_MAX_GROUPS:       # a group nobody came for: the oldest goes
-            _, (_, futs) = next(iter(self._prefetched.items()))
-            for f in futs:
-                f.cancel()
-            del self._prefetched[next(iter(self._prefetched))]
-        self._prefetched[key] = (images, [self._prefetch_pool.submit(self._host_prepare, im) for im in images])
+        for im in images:
+            if id(im) in self._prefetched:
+                continue
+            while len(self._prefetched) >= self._PREFETCH_MAX_GROUPS * 8:
+                _, (_, fut) = self._prefetched.popitem(last=False)
+                fut.cancel()
+            self._prefetched[id(im)] = (im, self._prefetch_pool.submit(self._host_prepare, im))     # (the image is kept alive: its id stays its own)
 
     def close_prefetch(self):
-        """stop the host-preparation thread (pending groups are dropped)"""
+        """stop the host-preparation thread (pending images are dropped)"""
         pool = getattr(self, "_prefetch_pool", None)
         if pool is not None:
             pool.shutdown(wait=True)
@@ -207,15 +208,18 @@ class Hunyuan3DDiTPipeline:
             self._prefetched = {}
 
     def _prepared(self, images):
-        """the prepared conditioner inputs of `images`: from a prefetch when one was made for exactly these objects"""
+        """the prepared conditioner inputs of `images`: from the prefetch where one was started for the same image object"""
         pending = getattr(self, "_prefetched", None)
-        if pending:
-            hit = pending.pop(tuple(id(im) for im in images), None)
-            if hit is not None:
+        out = []
+        for im in images:
+            hit = pending.pop(id(im), None) if pending else None
+            if hit is not None and hit[0] is im and not hit[1].cancelled():
                 with self._timings_lock():
-                    self.timings["prefetch_hits"] = self.timings.get("prefetch_hits", 0) + len(images)
-                return [f.result() for f in hit[1]]
-        return [self._host_prepare(im) for im in images]
+                    self.timings["prefetch_hits"] = self.timings.get("prefetch_hits", 0) + 1
+                out.append(hit[1].result())
+            else:
+                out.append(self._host_prepare(im))
+        return out
 
     def prepare_latents(self, generator):
         shape = (self.model.num_latents, self.model.in_channels)

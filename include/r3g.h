@@ -427,11 +427,15 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * the sum of a lane's 16 exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its query tile
  * again with variant 0's body | 0 = rounds 2-5.  Bit-identical to variant 0 unless variant 0 would have moved its stabiliser where
  * the fast pass does not: then equal within the bf16 rounding of P),
+ * "geo_lnd_fused" (1 default, round 6 | 0: the geo decoder's ln_post + output_proj as their own launch over the stored residual
+ * stream, rounds 1-5; fused, the last residual GEMM's epilogue writes per-row statistics of its 64-column chunks instead of the
+ * stream and a small kernel merges them -- same function, another summation order: logits equal to ~1e-6 of their scale),
  * "gemm_epi_slices" (1 default, round 6 | 0: the persistent phased kernel's bf16 / fused-QKV epilogues in 32-row passes through 4 KiB of
  * extra scratch per wave instead of 64-row passes through the wave's own staging slices of the idle k-tile buffer), "gemm_mixed" (1
  * default, round 6 | 0: a DiT single block's fused QKV projection and MLP-in + GELU projection as two launches instead of one
- * persistent launch over both problems' tiles), "gemm_persistent_qkv" (0 default | 1: fused QKV launches with more 256x256 tiles than CUs on the persistent phased kernel,
- * their epilogue in passes of 32 rows -- measured 17 ms per object slower, profiles/r04_gemm_stream.md), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive
+ * persistent launch over both problems' tiles), "gemm_persistent_qkv" (1 default since round 6 | 0: fused QKV launches with more 256x256 tiles than CUs -- the double
+ * blocks' img + txt pair -- one tile per workgroup instead of the persistent phased kernel; with round 4's 32-row epilogue passes the
+ * persistent form was 17 ms per object slower, with "gemm_epi_slices" it is 4 ms faster, profiles/r06_ab.md), "flow_first_step" / "flow_last_step" (0 / -1: r3g_flow_sample runs steps [first, last) of its schedule; consecutive
  * segments continuing on each other's latents are the same launches as one call -- how tests read the latents after 10, 20, ...
  * of 50 steps).  None of them changes a
  * result bit, except fuse_qkv / batch_mods / cfg_dedup (different summation order, same function) and attn_generation

@@ -295,15 +295,17 @@ def test_linear1_as_one_persistent_launch_and_sliced_epilogues_are_bit_identical
     lat, cond = _batch_inputs(wide, 4, 300)
     want = wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0).clone()
     try:
-        for mixed, slices in ((0, 1), (1, 0), (0, 0)):
+        for mixed, slices, pqkv in ((0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0), (0, 0, 0)):
             ffi.check(L.r3g_set_option(b"gemm_mixed", mixed))
             ffi.check(L.r3g_set_option(b"gemm_epi_slices", slices))
+            ffi.check(L.r3g_set_option(b"gemm_persistent_qkv", pqkv))       # the double blocks' QKV pair on the persistent kernel
             got = wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0)
-            assert torch.equal(got, want), "gemm_mixed=%d gemm_epi_slices=%d: max |d| %.3e" % (
-                mixed, slices, float((got - want).abs().max()))
+            assert torch.equal(got, want), "gemm_mixed=%d gemm_epi_slices=%d gemm_persistent_qkv=%d: max |d| %.3e" % (
+                mixed, slices, pqkv, float((got - want).abs().max()))
     finally:
         ffi.check(L.r3g_set_option(b"gemm_mixed", 1))
         ffi.check(L.r3g_set_option(b"gemm_epi_slices", 1))
+        ffi.check(L.r3g_set_option(b"gemm_persistent_qkv", 1))
     for _ in range(2):                                   # stable from run to run (an LDS hazard would show as rare diffs)
         assert torch.equal(wide.gpu.flow_sample_batch(lat.clone(), cond, 2, 5.0), want)
 
@@ -603,6 +605,34 @@ def test_layernorm_instantiations_are_bit_identical(wide):
                            % (name, fixed, rows, int((a != b).sum()), float((a.float() - b.float()).abs().max())))
     assert not bad, "; ".join(bad)
     assert all(torch.isfinite(t.float()).all() for t in outs[0])
+
+
+def test_ln_post_and_output_proj_inside_the_last_residual_gemm(wide):
+    """Round 6, option geo_lnd_fused (default): the geo decoder's last residual GEMM writes per-row statistics of its 64-column chunks
+    (sum, squared deviations from the chunk mean, dot with gamma * w) instead of the stream, and a small kernel merges them (Chan's
+    formula) into the logits -- the same function as the ln_dot launch over the stored stream, another summation order."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    lat = torch.randn(3072, 64, generator=torch.Generator().manual_seed(5))
+    wide.gpu.vae_decode(lat, return_z=True)
+    R = 256
+    outs = {}
+    try:
+        for fused in (1, 0):
+            ffi.check(L.r3g_set_option(b"geo_lnd_fused", fused))
+            for start, count in ((257 * 257 * 100 + 12345, 3000), (0, 2 * 131072 + 777)):     # a ragged slice; two canonical passes + a tail
+                out = torch.zeros(257 ** 3, device="cuda")
+                wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+                outs[(fused, start)] = out[start:start + count].cpu().clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"geo_lnd_fused", 1))
+    for start in (257 * 257 * 100 + 12345, 0):
+        a, b = outs[(1, start)], outs[(0, start)]
+        assert torch.isfinite(a).all()
+        d = float((a - b).abs().max() / b.abs().max())
+        report("geo decoder: ln_post + output_proj fused into the last GEMM vs the ln_dot launch (start %d)" % start, d, 1e-5)
+        assert d <= 1e-5
 
 
 def test_geo_decoder_fp8_mode(wide):

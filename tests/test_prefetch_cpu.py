@@ -62,9 +62,9 @@ def test_prefetched_inputs_equal_the_direct_ones_and_run_on_the_worker_thread():
         got2 = p._prepared(other)
         assert all(torch.equal(a, b) for a, b in zip(got2, direct[:2]))
         assert seen.count(threading.current_thread().name) == 2
-        # a second prefetch does not displace the first; a single image is a group of one
+        # (round 6: kept per image) a second prefetch of an image that is already pending changes nothing; a single image is accepted
         p.prefetch(imgs[2])
-        assert len(p._prefetched) == 2
+        assert len(p._prefetched) == 3
         assert torch.equal(p._prepared([imgs[2]])[0], direct[2])
         assert all(torch.equal(a, b) for a, b in zip(p._prepared(imgs), direct)) and p._prefetched == {}
         assert torch.get_num_threads() == before
@@ -100,13 +100,33 @@ def test_no_crop_is_prepared_twice_when_the_next_group_is_prefetched_before_the_
     # groups nobody comes for do not pile up
     p2 = _pipeline()
     try:
-        keep = [[_crop(100 + g)] for g in range(7)]
+        keep = [[_crop(100 + g)] for g in range(p2._PREFETCH_MAX_GROUPS * 8 + 5)]
         for grp in keep:
             p2.prefetch(grp)
-        assert len(p2._prefetched) == p2._PREFETCH_MAX_GROUPS
+        assert len(p2._prefetched) == p2._PREFETCH_MAX_GROUPS * 8
         assert torch.equal(p2._prepared(keep[-1])[0], p2._host_prepare(keep[-1][0]))
     finally:
         p2.close_prefetch()
+
+
+def test_groups_cut_differently_from_the_prefetches_still_prepare_every_crop_once():
+    """bench.py's warm-up of 5 crops in groups of 4: the prefetch covers crops 4..7, the next call takes crop 4 alone and the
+    timed run then starts with crops 5..8 ('20 of 34' -- five crops were prepared twice)"""
+    p = _pipeline()
+    crops = [_crop(200 + i) for i in range(9)]
+    calls = []
+    orig = p._host_prepare
+    p._host_prepare = lambda im: (calls.append(id(im)), orig(im))[1]
+    try:
+        p.prefetch(crops[0:4])
+        p.prefetch(crops[4:8])
+        p._prepared(crops[0:4])
+        p.prefetch(crops[8:9])
+        p._prepared(crops[4:5])
+        p._prepared(crops[5:9])
+    finally:
+        p.close_prefetch()
+    assert len(calls) == 9 and len(set(calls)) == 9 and p.timings["prefetch_hits"] == 9
 
 
 def test_a_crop_that_cannot_be_prepared_raises_at_pick_up():

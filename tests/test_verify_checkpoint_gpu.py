@@ -20,7 +20,7 @@ def test_the_tool_passes_a_synthetic_snapshot_and_reports_the_stream_magnitudes(
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     s = rep["shape"]
     assert rep["ok"] and s["keys"]["ok"]
-    assert len(s["blocks"]) == 2 + 4 and all(b["delta_rel_l2"] <= 5e-3 for b in s["blocks"])       # tiny config: 2 double + 4 single
+    assert len(s["blocks"]) == 2 + 3 and all(b["delta_rel_l2"] <= 5e-3 for b in s["blocks"])       # tiny config: 2 double + 3 single
     assert 0 < s["max_abs_residual"] < 65504 and s["fp16_stream_has_headroom"]
     assert s["sampling"]["dit_f16_fallbacks"] == 0 and s["sampling"]["fp16_stream"] <= 2e-2 and s["sampling"]["fp32_stream"] <= 2e-2
     assert s["vae_rel_l2"] <= 8e-3 and s["grid_logits_max_err_over_max"] <= 1e-2
