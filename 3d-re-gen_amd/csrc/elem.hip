@@ -757,6 +757,65 @@ __global__ __launch_bounds__(256) void lnd_finalize_kernel(const float4* __restr
     out[r] = rsqrtf(M2 / N + eps) * (D - mean * consts[0]) + consts[1];
 }
 
+// ---- ln_3 fold (EPI_RESID_BF16_ST / EPI_BF16_GELU_ERF_LNF) ---------------------------------------------------------------------
+// One wave per output row n: W'[n][k] = bf16(W[n][k] * gamma[k]); c1[n] = sum_k W'[n][k] (of the ROUNDED values: the algebra
+// LN(x) W^T = rstd (x W'^T - mean c1) + c2 is then exact in W'); c2[n] = sum_k beta[k] W[n][k] + b[n].  K % 64 == 0.
+__global__ __launch_bounds__(256) void lnf_prepare_kernel(const uint16_t* __restrict__ w, int64_t ldw, const float* __restrict__ b,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
+                                                          uint16_t* __restrict__ w2, float* __restrict__ c1, float* __restrict__ c2) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = __uint_as_float((uint32_t)w[(int64_t)n * ldw + k] << 16);
+        const uint16_t r = f2bf(wv * gamma[k]);
+        w2[(int64_t)n * K + k] = r;
+        a1 += __uint_as_float((uint32_t)r << 16);
+        a2 = fmaf(beta[k], wv, a2);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a1 += __shfl_xor(a1, d, 64);
+        a2 += __shfl_xor(a2, d, 64);
+    }
+    if (lane == 0) {
+        c1[n] = a1;
+        c2[n] = a2 + (b ? b[n] : 0.f);
+    }
+}
+
+// chunk statistics [rows][parts][4] -> (mean, rstd) per row (the same merge as lnd_finalize_kernel)
+__global__ __launch_bounds__(256) void lnf_stats_kernel(const float4* __restrict__ part, int rows, int parts, float eps,
+                                                        float2* __restrict__ stats) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float4* p = part + (int64_t)r * parts;
+    float S = 0.f;
+    for (int i = 0; i < parts; ++i) S += p[i].x;
+    const float N = 64.0f * (float)parts;
+    const float mean = S / N;
+    float M2 = 0.f;
+    for (int i = 0; i < parts; ++i) {
+        const float dm = p[i].x * (1.0f / 64.0f) - mean;
+        M2 += p[i].y + 64.0f * dm * dm;
+    }
+    stats[r] = make_float2(mean, rsqrtf(M2 / N + eps));
+}
+
+hipError_t lnf_prepare_launch(const uint16_t* w, int64_t ldw, const float* b, const float* gamma, const float* beta, int N, int K,
+                              uint16_t* w2, float* c1, float* c2, hipStream_t s) {
+    if (K % 64 || !gamma || !beta) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lnf_prepare_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, ldw, b, gamma, beta, N, K, w2, c1, c2);
+    return hipGetLastError();
+}
+
+hipError_t lnf_stats_launch(const float* part, int rows, int parts, float eps, float* stats, hipStream_t s) {
+    ProfScope prof_scope_(PC_LAYERNORM, 0.0, s);
+    hipLaunchKernelGGL(lnf_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const float4*)part, rows, parts, eps, (float2*)stats);
+    return hipGetLastError();
+}
+
 hipError_t lnd_prepare_launch(const float* lnw, const float* lnb, const float* w, float b, int N, float* gw, float* consts, hipStream_t s) {
     hipLaunchKernelGGL(lnd_prepare_kernel, dim3(1), dim3(256), 0, s, lnw, lnb, w, b, N, gw, consts);
     return hipGetLastError();

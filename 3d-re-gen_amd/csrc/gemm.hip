@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                                               int wc, int lane, char* lds_wave = nullptr, const f32x4* bias_pre = nullptr) {
     constexpr int WROWS = MI * 16;
     static_assert(MI % PI == 0, "scratch passes");
-    static_assert(SLICE == 2048 || ((EPI == EPI_QKV || EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) && PI == 4),
+    static_assert(SLICE == 2048 || ((EPI == EPI_QKV || EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_BF16_GELU_ERF_LNF) && PI == 4),
                   "sliced scratch: 64-row passes of 128-byte rows");
     // byte offset of row R of a scratch of 128-byte rows
     auto roff = [](int R) __attribute__((always_inline)) { return SLICE == 2048 ? R * 128 : (R >> 4) * SLICE + (R & 15) * 128; };
@@ -373,9 +373,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         }
         return;
     }
-    if constexpr (EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16 || EPI == EPI_RESID_BF16_LND) {
+    if constexpr (EPI == EPI_RESID_BF16 || EPI == EPI_RESID_F16 || EPI == EPI_RESID_BF16_LND || EPI == EPI_RESID_BF16_ST) {
         constexpr bool F16 = EPI == EPI_RESID_F16;
-        constexpr bool LND = EPI == EPI_RESID_BF16_LND;   // the new values are not stored: per-row chunk statistics instead (kernels.h)
+        constexpr bool ST = EPI == EPI_RESID_BF16_ST;     // stored AND per-row chunk statistics (kernels.h)
+        constexpr bool LND = EPI == EPI_RESID_BF16_LND || ST;   // LND proper: the new values are not stored, statistics + dot instead
         // bf16 residual stream: x = bf16(x + gate * (acc + bias)), the sum formed in fp32.
         uint16_t* X = reinterpret_cast<uint16_t*>(p.C) + (int64_t)batch * p.strideC;
         const uint16_t* XR = p.resid_src ? p.resid_src + (int64_t)batch * p.strideC : X;   // where the old values come from
@@ -400,7 +401,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             const int cc = lane & 7;
             const int n = n0 + wc * 64 + cc * 8;
             f32x4 gw0 = (f32x4){0.f, 0.f, 0.f, 0.f}, gw1 = gw0;
-            if constexpr (LND) {
+            if constexpr (LND && !ST) {
                 const int nc = n < p.N ? n : p.N - 8;
                 gw0 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc);
                 gw1 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc + 4);
@@ -466,7 +467,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         m2 += __shfl_xor(m2, 4, 64); s3 += __shfl_xor(s3, 4, 64);
                         if (cc == 0 && m < p.M && n < p.N)
                             *reinterpret_cast<f32x4*>(p.lnd_part + ((int64_t)m * (p.N >> 6) + ((n0 >> 6) + wc)) * 4) = (f32x4){s1, m2, s3, 0.f};
-                    } else {
+                    }
+                    if constexpr (!LND || ST) {
                         if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
                     }
                 }
@@ -600,6 +602,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         const bool wide = EPI != EPI_F32 && lds_wave != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
                           (p.strideC & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
         if (VM0 && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // LNF (round 6): the LayerNorm of A's rows folded into this GEMM -- v = rstd[m] (acc - mean[m] c1[n]) + c2[n] (c2 = p.bias)
+        constexpr bool LNF = EPI == EPI_BF16_GELU_ERF_LNF;
+        f32x4 c1v[4];
+        f32x2 st[MI];
+        if constexpr (LNF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ncol + j * 16;
+                c1v[j] = *reinterpret_cast<const f32x4*>(p.lnf_c1 + (n < p.N ? n : p.N - 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mrow + i * 16;
+                st[i] = *reinterpret_cast<const f32x2*>(p.lnf_stats + 2 * (int64_t)(m < p.M ? m : p.M - 1));
+            }
+        }
         // PK: the GELU epilogues in packed fp16 (gemm_common.h; run-time option "gelu_pk", one wave-uniform branch per tile)
         auto body = [&](auto PKC) __attribute__((always_inline)) {
         constexpr bool PK = decltype(PKC)::value;
@@ -612,8 +630,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     const int i = ip + ii;
                     const int n = ncol + j * 16, m = mrow + i * 16;
                     f32x4 v = acc[j][i] + biasv[j];
+                    if constexpr (LNF) v = st[i][1] * (acc[j][i] - st[i][0] * c1v[j]) + biasv[j];
                     if (EPI == EPI_BF16_GELU_TANH) v = gelu_tanh4<PK>(v);
-                    else if (EPI == EPI_BF16_GELU_ERF) v = gelu_erf4<PK>(v);
+                    else if (EPI == EPI_BF16_GELU_ERF || LNF) v = gelu_erf4<PK>(v);
                     if (EPI != EPI_F32 && wide) {
                         uint2 pk;
                         pk.x = pack_bf16(v[0], v[1]);
@@ -653,7 +672,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             }
         }
         };
-        if constexpr (EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF) {
+        if constexpr (EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_BF16_GELU_ERF_LNF) {
             if (p.gelu_pk) body(std::true_type{});
             else body(std::false_type{});
         } else {
@@ -1779,7 +1798,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
             const GemmArgs& pp = args_of(done.second);
             auto run = [&](auto E) __attribute__((always_inline)) {
                 constexpr int epi = decltype(E)::value;
-                constexpr bool kPre = epi == EPI_BF16 || epi == EPI_BF16_GELU_TANH || epi == EPI_BF16_GELU_ERF;
+                constexpr bool kPre = epi == EPI_BF16 || epi == EPI_BF16_GELU_TANH || epi == EPI_BF16_GELU_ERF || epi == EPI_BF16_GELU_ERF_LNF;
                 constexpr bool kSl = SLICED && (kPre || epi == EPI_QKV);
                 if constexpr (kSl)
                     gemm_epilogue<epi, MI, true, 4, false, HALF>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
@@ -1820,7 +1839,7 @@ hipError_t launch_gemm8p(const GemmArgs& p, const GemmArgs& p2, int num_cu, hipS
     const int rounds = (tiles + num_cu - 1) / num_cu;
     const int grid = (tiles + rounds - 1) / rounds;    // every workgroup gets `rounds` tiles (the last ones one fewer)
     const size_t lds = 163840;
-    constexpr bool kSliceable = EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_QKV;
+    constexpr bool kSliceable = EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_QKV || EPI == EPI_BF16_GELU_ERF_LNF;
     auto k = gemm8p_kernel<EPI, false, EPI2>;
     auto ks = gemm8p_kernel<EPI, kSliceable, EPI2>;
     static int state = 0;   // 0 unknown, 1 usable, -1 the device refuses 160 KiB of LDS
@@ -2223,6 +2242,21 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
                                    p.bias, p.gate, reinterpret_cast<float*>(p.C), p.ldc);
             return hipGetLastError();
         }
+    }
+    if (p.epi == EPI_RESID_BF16_ST) {
+        const uint16_t* xr = p.resid_src ? p.resid_src : reinterpret_cast<const uint16_t*>(p.C);
+        if (p2.M > 0 || batch != 1 || !g_gemm_glds || !p.wide_epilogue || !p.lnd_part || p.K % 128 || p.K < 256 || p.N % 256 || (p.ldc & 7) ||
+            (reinterpret_cast<uintptr_t>(p.C) & 15) || (reinterpret_cast<uintptr_t>(xr) & 15) || (reinterpret_cast<uintptr_t>(p.lnd_part) & 15))
+            return hipErrorInvalidValue;
+        return launch_gemm8<EPI_RESID_BF16_ST>(p, p2, s);
+    }
+    if (p.epi == EPI_BF16_GELU_ERF_LNF) {
+        // one problem on the persistent phased kernel (bf16 output through the sliced LDS transpose)
+        const long tiles = (long)(p.N / 256) * ((p.M + 255) / 256);
+        if (p2.M > 0 || batch != 1 || !g_gemm_glds || !p.wide_epilogue || !p.lnf_c1 || !p.lnf_stats || !p.bias || p.K % 128 || p.K < 256 ||
+            p.N % 256 || (p.ldc & 7) || (reinterpret_cast<uintptr_t>(p.C) & 15) || tiles < 1)
+            return hipErrorInvalidValue;
+        return launch_gemm8p<EPI_BF16_GELU_ERF_LNF>(p, p2, g_num_cu, s);
     }
     if (p.epi == EPI_RESID_BF16_LND) {
         // one problem on the phased 256 x 256 kernel, wide read-modify-write epilogue (its alignment rules checked here: the

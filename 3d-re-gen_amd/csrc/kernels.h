@@ -22,6 +22,10 @@ enum GemmEpilogue {
     // from the chunk mean, sum of x * lnd_gw[n]} -- to lnd_part[row][N / 64][4]; lnd_finalize_launch merges the chunks (Chan's
     // formula, fixed order) into logit = rstd * (dot - mean * sum(gw)) + const.  One problem, 256 x 256 phased kernel only.
     EPI_RESID_BF16_LND = 9,
+    // Round 6, the geo decoder's ln_3 folded into the GEMMs around it (weights are static, so LN(x) W^T = rstd (x W'^T - mu c1) + c2
+    // with W' = bf16(W * gamma), c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] W[n][k] + b[n]):
+    EPI_RESID_BF16_ST = 10,        // EPI_RESID_BF16 that ALSO writes the per-row chunk statistics {sum, squared deviations} to lnd_part
+    EPI_BF16_GELU_ERF_LNF = 11,    // C(bf16) = gelu_erf(rstd[m] (acc - mu[m] lnf_c1[n]) + bias[n]), (mu, rstd) = lnf_stats[m]; A = the raw stream
 };
 
 enum QkNorm { QKN_NONE = 0, QKN_RMS = 1, QKN_LAYERNORM = 2 };
@@ -97,7 +101,9 @@ struct GemmArgs {
     int64_t split_ws_elems;
     ConvA conv;         // conv.x != null: A is the implicit im2col matrix of conv.x (fp32 epilogues, one problem, 128x128 kernel)
     const float* lnd_gw;   // EPI_RESID_BF16_LND: ln_post.weight[n] * output_proj.weight[n], f32 [N]
-    float* lnd_part;       // EPI_RESID_BF16_LND: f32 [M][N / 64][4]
+    float* lnd_part;       // EPI_RESID_BF16_LND / _ST: f32 [M][N / 64][4]
+    const float* lnf_c1;   // EPI_BF16_GELU_ERF_LNF: f32 [N]
+    const float* lnf_stats;   // EPI_BF16_GELU_ERF_LNF: f32 [M][2] = (mean, rstd) of the rows of A
 };
 
 hipError_t gemm_launch(const GemmArgs& p, int batch, hipStream_t s);
@@ -235,6 +241,10 @@ hipError_t fourier_grid_launch(uint16_t* out, int64_t start, int count, int R, d
 // EPI_RESID_BF16_LND's two small kernels (elem.hip): gw[n] = lnw[n] * w[n], consts = {sum gw, sum lnb[n] w[n] + b}; and the merge of the
 // per-chunk statistics into out[row] = rstd * (dot - mean * consts[0]) + consts[1]
 hipError_t lnd_prepare_launch(const float* lnw, const float* lnb, const float* w, float b, int N, float* gw, float* consts, hipStream_t s);
+// ln_3 fold: W' = bf16(W * gamma) [N][K], c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] W[n][k] + b[n];  (mean, rstd) per row from the chunk statistics
+hipError_t lnf_prepare_launch(const uint16_t* w, int64_t ldw, const float* b, const float* gamma, const float* beta, int N, int K,
+                              uint16_t* w2, float* c1, float* c2, hipStream_t s);
+hipError_t lnf_stats_launch(const float* part, int rows, int parts, float eps, float* stats, hipStream_t s);
 hipError_t lnd_finalize_launch(const float* part, int rows, int parts, float eps, const float* consts, float* out, hipStream_t s);
 hipError_t ln_dot_launch(const float* x, int64_t ldx, int rows, int C, int do_ln, const float* lnw, const float* lnb, float eps,
                          const float* w, float b, float* out, hipStream_t s, int x_bf16 = 0);

@@ -61,6 +61,7 @@ static unsigned g_option_epoch = 0;   // bumped by every r3g_set_option: cached 
 static long long g_geo_q_cache_bytes = -1;   // budget of that cache in bytes (option "geo_q_cache_gb"); < 0: 30 % of the device's memory
 static bool g_geo_q_cache = true;   // keep the object-independent query side of the geo decoder resident in HBM (Model::GeoCache)
 static bool g_dit_f16_guard = true;    // option "dit_f16_guard": check the latents of an fp16-stream group, fall back to fp32 on overflow
+static bool g_geo_ln3_fold = true;    // option "geo_ln3_fold" (round 6): the geo decoder's ln_3 folded into c_proj's epilogue (statistics) and c_fc (W' = W gamma, rstd (acc - mean c1) + c2)
 static bool g_geo_lnd_fused = true;   // option "geo_lnd_fused" (round 6): ln_post + output_proj folded into the geo decoder's last residual GEMM
 static int64_t g_dit_groups = 0;         // launch groups r3g_flow_sample_batch has run (r3g_get_counter)
 static int g_dit_f16_fallbacks = 0;    // how often that happened (r3g_set_option("dit_f16_fallbacks_reset", ...) / stderr line)
@@ -107,6 +108,8 @@ struct Model {
     struct W8 { uint8_t* w8; float* sw; };
     std::unordered_map<const void*, W8> w8;
     float *fp8_sa = nullptr, *fp8_sconst = nullptr;
+    uint16_t* lnf_w = nullptr;                       // ln_3 fold: bf16(c_fc.weight * ln_3.weight) [N][W]
+    float *lnf_c = nullptr, *lnf_stats = nullptr;    //   c1 | c2 [2 N], (mean, rstd) per row of a pass [qc][2]
     float *lnd_gw = nullptr, *lnd_part = nullptr;   // EPI_RESID_BF16_LND: gamma * w [W] + 2 constants, chunk statistics [qc][W / 64][4]
     // activation arena of the CFG-de-duplicated DiT for `cap` objects per launch (allocated on first use), and the segment
     // tables of its fused QKV epilogues for `nb` objects
@@ -867,12 +870,25 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
     // Round 6: ln_post + output_proj inside the last residual GEMM (EPI_RESID_BF16_LND): the final stream x2 is never written or
     // read again (2 x 268 MB per pass) and the ln_dot launch becomes a 33 MB merge of per-chunk statistics.  bf16 stream, bf16 MLP.
     const bool lnd = g_geo_lnd_fused && xb && !f8m && c.vae_ln_post && W % 256 == 0 && W <= 4096 && lfc.N % 128 == 0 && lfc.N >= 256;
+    // ... and ln_3 the same way, its weights being static: c_proj's epilogue also writes the row statistics of the stream it stores
+    // (EPI_RESID_BF16_ST), a small kernel merges them into (mean, rstd), and c_fc runs on the RAW stream with W' = bf16(W gamma) and the
+    // epilogue rstd (acc - mean c1) + c2 in front of its GELU (EPI_BF16_GELU_ERF_LNF) -- no LayerNorm launch, no normalised copy of the
+    // stream (2 x 268 MB per pass).
+    const bool lnf = g_geo_ln3_fold && xb && !f8m && W % 256 == 0 && W <= 4096 && lfc.N % 256 == 0;
+    if ((lnd || lnf) && !m.lnd_part) R3G_TRY(hipMalloc((void**)&m.lnd_part, 16 * (size_t)m.qc * (size_t)(W / 64)));
     if (lnd) {
-        if (!m.lnd_gw) {
-            R3G_TRY(hipMalloc((void**)&m.lnd_gw, 4 * (size_t)(W + 64)));
-            R3G_TRY(hipMalloc((void**)&m.lnd_part, 16 * (size_t)m.qc * (size_t)(W / 64)));
-        }
+        if (!m.lnd_gw) R3G_TRY(hipMalloc((void**)&m.lnd_gw, 4 * (size_t)(W + 64)));
         R3G_TRY(lnd_prepare_launch(lpw, lpb, ow, ob, W, m.lnd_gw, m.lnd_gw + W, s));      // (per call: the weights may have been re-registered)
+    }
+    Lin lfc2 = lfc;
+    if (lnf) {
+        if (!m.lnf_w) {
+            R3G_TRY(hipMalloc((void**)&m.lnf_w, 2 * (size_t)lfc.N * (size_t)W));
+            R3G_TRY(hipMalloc((void**)&m.lnf_c, 4 * 2 * (size_t)lfc.N));
+            R3G_TRY(hipMalloc((void**)&m.lnf_stats, 8 * (size_t)m.qc));
+        }
+        R3G_TRY(lnf_prepare_launch(lfc.w, lfc.ldw, lfc.b, l3w, l3b, lfc.N, W, m.lnf_w, m.lnf_c, m.lnf_c + lfc.N, s));
+        lfc2.w = m.lnf_w; lfc2.ldw = W; lfc2.K = W; lfc2.b = m.lnf_c + lfc.N;
     }
     for (int64_t off = 0; off < count; off += m.qc) {
         const int n = (int)std::min<int64_t>(m.qc, count - off);
@@ -914,7 +930,8 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
         }
         R3G_RC(attention(m, 1, heads, n, npad, Nl, Lkp, m.cat, W, 0, m.geoK, m.geoVt, true, s, Qp));
         {   // x1 = x0 + c_proj(attention): the old values come from the cached x0 where there is one
-            GemmArgs pr = gemm_args(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, epi_res, nullptr, 0);
+            GemmArgs pr = gemm_args(m.cat, W, 0, lproj, 0, W, m.f32a, W, 0, n, W, lnf ? (int)EPI_RESID_BF16_ST : epi_res, nullptr, 0);
+            pr.lnd_part = m.lnd_part;
             if (canon) pr.resid_src = x0;
             hipError_t e = gemm_launch(pr, 1, s);
             if (e != hipSuccess) return hip_fail(e, "gemm_launch(geo c_proj)");
@@ -924,8 +941,18 @@ static int grid_query(Model& m, double bound, int R, float* grid, int64_t start,
             R3G_RC(gemm_fp8(m, xn8, m.fp8_sa, lfc, hid8, lfc.N, n, EPI_FP8_GELU_ERF, nullptr, 0, s));
             R3G_RC(gemm_fp8(m, hid8, m.fp8_sconst, lfp, m.f32a, W, n, epi_res, nullptr, 0, s));
         } else {
-            R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
-            R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+            if (lnf) {
+                R3G_TRY(lnf_stats_launch(m.lnd_part, n, W / 64, 1e-6f, m.lnf_stats, s));
+                GemmArgs pf = gemm_args(reinterpret_cast<const uint16_t*>(m.f32a), W, 0, lfc2, 0, lfc.N, m.hid, lfc.N, 0, n, W,
+                                        EPI_BF16_GELU_ERF_LNF, nullptr, 0);
+                pf.lnf_c1 = m.lnf_c;
+                pf.lnf_stats = m.lnf_stats;
+                hipError_t e = gemm_launch(pf, 1, s);
+                if (e != hipSuccess) return hip_fail(e, "gemm_launch(geo ln_3 + mlp.c_fc)");
+            } else {
+                R3G_RC(layernorm(m.f32a, W, 0, m.xn, W, 0, n, 1, W, l3w, l3b, nullptr, nullptr, 0, 1e-6f, s, xb));
+                R3G_RC(gemm(m.xn, W, 0, lfc, 0, lfc.N, m.hid, lfc.N, 0, n, W, EPI_BF16_GELU_ERF, nullptr, 0, 1, s));
+            }
             if (lnd) {
                 GemmArgs pl = gemm_args(m.hid, lfc.N, 0, lfp, 0, W, m.f32a, W, 0, n, lfc.N, EPI_RESID_BF16_LND, nullptr, 0);
                 pl.lnd_gw = m.lnd_gw;
@@ -1005,6 +1032,9 @@ static void model_free(Model* m) {
         (void)hipFree(kv.second.sw);
     }
     if (m->fp8_sa) (void)hipFree(m->fp8_sa);
+    if (m->lnf_w) (void)hipFree(m->lnf_w);
+    if (m->lnf_c) (void)hipFree(m->lnf_c);
+    if (m->lnf_stats) (void)hipFree(m->lnf_stats);
     if (m->lnd_gw) (void)hipFree(m->lnd_gw);
     if (m->lnd_part) (void)hipFree(m->lnd_part);
     if (m->fp8_sconst) (void)hipFree(m->fp8_sconst);
@@ -1375,6 +1405,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "conv_implicit")) gemm_set_conv_implicit(value != 0);
     else if (!strcmp(name, "gemm_xcd_walk")) gemm_set_xcd_walk(value != 0);
     else if (!strcmp(name, "geo_lnd_fused")) g_geo_lnd_fused = value != 0;
+    else if (!strcmp(name, "geo_ln3_fold")) g_geo_ln3_fold = value != 0;
     else if (!strcmp(name, "attn_variant")) attn_set_variant(value);
     else if (!strcmp(name, "gemm_epi_slices")) gemm_set_epi_slices(value != 0);
     else if (!strcmp(name, "gemm_mixed")) gemm_set_mixed(value != 0);

@@ -427,6 +427,10 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * the sum of a lane's 16 exponentials against 2^16 into a sticky flag; a workgroup whose valid queries set it runs its query tile
  * again with variant 0's body | 0 = rounds 2-5.  Bit-identical to variant 0 unless variant 0 would have moved its stabiliser where
  * the fast pass does not: then equal within the bf16 rounding of P),
+ * "geo_ln3_fold" (1 default, round 6 | 0: the geo decoder's ln_3 as its own launch writing a normalised bf16 copy of the stream, rounds
+ * 1-5; folded, c_proj's epilogue also writes the rows' chunk statistics, and c_fc runs on the raw stream with W' = bf16(W gamma) and
+ * rstd (acc - mean c1) + c2 in front of its GELU -- the same function without the bf16 rounding of the normalised operand: logits move
+ * by ~1e-3 of their scale, inside the 1e-2 tolerance against the fp32 oracle),
  * "geo_lnd_fused" (1 default, round 6 | 0: the geo decoder's ln_post + output_proj as their own launch over the stored residual
  * stream, rounds 1-5; fused, the last residual GEMM's epilogue writes per-row statistics of its 64-column chunks instead of the
  * stream and a small kernel merges them -- same function, another summation order: logits equal to ~1e-6 of their scale),

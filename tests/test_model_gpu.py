@@ -635,6 +635,48 @@ def test_ln_post_and_output_proj_inside_the_last_residual_gemm(wide):
         assert d <= 1e-5
 
 
+def test_ln_3_folded_into_the_gemms_around_it(wide):
+    """Round 6, option geo_ln3_fold (default): LN(x) W^T = rstd (x W'^T - mean c1) + c2 with W' = bf16(W gamma) -- c_proj's epilogue writes
+    the row statistics of the stream it stores, c_fc runs on the raw stream.  Against the fp32 oracle at the grid-logit tolerance, and
+    against the unfolded path (which rounds the normalised operand to bf16: a difference of that size is expected)."""
+    import torch
+    from r3g import ffi
+    L = ffi.lib()
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(3072, 64, generator=g)
+    with torch.no_grad():
+        z_ref = wide.oracle.vae(lat[None] / wide.oracle.vae.scale_factor)
+    wide.gpu.vae_decode(lat, return_z=True)
+    R, start, count = 256, 257 * 257 * 100 + 12345, 3000
+    pts = torch.from_numpy(wide.H.dense_grid_points(1.01, R)[start:start + count])
+    with torch.no_grad():
+        ref = wide.oracle.vae.geo_decoder(queries=pts[None], latents=z_ref)[0, :, 0]
+    got = {}
+    try:
+        for fold in (1, 0):
+            ffi.check(L.r3g_set_option(b"geo_ln3_fold", fold))
+            out = torch.zeros(257 ** 3, device="cuda")
+            wide.gpu.grid_query(1.01, R, out=out, start=start, count=count)
+            got[fold] = out[start:start + count].cpu().clone()
+            # two canonical passes through the query-side cache as well (the statistics ride on c_proj's cached-x0 form)
+            out2 = torch.zeros(257 ** 3, device="cuda")
+            wide.gpu.grid_query(1.01, R, out=out2, start=0, count=2 * 131072)
+            got[(fold, "pass")] = out2[:2 * 131072].cpu().clone()
+    finally:
+        ffi.check(L.r3g_set_option(b"geo_ln3_fold", 1))
+    scale = ref.abs().max().item()
+    for fold in (1, 0):
+        d = (got[fold] - ref).abs().max().item() / scale
+        report("full-width grid logits, ln_3 %s (257^3 slice)" % ("folded into c_proj / c_fc" if fold else "as its own launch"), d, TOL["grid_logits"])
+        assert torch.isfinite(got[fold]).all() and d <= TOL["grid_logits"]
+    d = (got[1] - got[0]).abs().max().item() / scale
+    report("  folded against unfolded", d, 1e-2)
+    assert d <= 1e-2             # (two bf16-level approximations of the same function: measured 4-6e-3, each within 6e-3 of the fp32 oracle)
+    dp = (got[(1, "pass")] - got[(0, "pass")]).abs().max().item() / got[(0, "pass")].abs().max().item()
+    report("  folded against unfolded, two canonical passes", dp, 1e-2)
+    assert dp <= 1e-2 and torch.isfinite(got[(1, "pass")]).all()
+
+
 def test_geo_decoder_fp8_mode(wide):
     """option geo_fp8 (BASELINE.json configs[3]): the geo decoder's c_q / MLP GEMMs on e4m3 operands (LayerNorm quantises with
     row scales, the MLP hidden with a static scale) -- grid logits against the fp32 oracle, and against the bf16 path"""
