@@ -2149,8 +2149,12 @@ static bool gemm_args_ok(const GemmArgs& p) {
 }
 
 // One launch for one problem (p2 == nullptr) or for two problems with the same epilogue (and hence kernel).
+static int g_last_splitk_slices = 1;     // the K slices the last gemm_launch2 actually ran with (r3g_op_gemm_splitk reports it; test hook)
+int gemm_last_splitk_slices() { return g_last_splitk_slices; }
+
 hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, int batch2, hipStream_t s) {
     GemmArgs p = p_in, p2{};
+    g_last_splitk_slices = 1;
     p.batch = batch;
     p.raster_group = g_gemm_raster;  // <0: automatic (4 tile-columns per group for 256x256 tiles, row-major otherwise)
     p.wide_epilogue = g_gemm_wide_epilogue ? 1 : 0;
@@ -2190,6 +2194,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
             if ((int64_t)S * MN > p.split_ws_elems) S = 1;
         }
         if (S > 1) {
+            g_last_splitk_slices = S;
             GemmArgs q = p;
             q.K = p.K / S;
             q.batch = S;
@@ -2219,6 +2224,7 @@ hipError_t gemm_launch2(const GemmArgs& p_in, int batch, const GemmArgs* p2_in, 
         const int S = splitk128_factor(p.M, p.N, p.K, g_num_cu);
         const int64_t MN = (int64_t)p.M * p.N;
         if (S > 1 && (int64_t)S * MN <= p.split_ws_elems) {
+            g_last_splitk_slices = S;
             GemmArgs q = p;
             q.K = p.K / S;
             q.batch = S;

@@ -127,6 +127,7 @@ void gemm_set_conv_implicit(bool on);   // the texture models' 3 x 3 convolution
 bool gemm_conv_implicit();              // ... and the staging path / tile override allow it right now
 void gemm_set_xcd_walk(bool on);        // persistent phased kernel: contiguous tile range per XCD (default on)
 void gemm_set_splitk128(bool on);    // split-K of the 128x128 kernel where GemmArgs::split_ws allows it (default on)
+int gemm_last_splitk_slices();          // the K slices the last gemm_launch / gemm_launch2 of this process actually ran with (1 = no split)
 int gemm_splitk128_factor(int M, int N, int K);   // the number of K slices the rule picks for one problem (1 = no split)
 void gemm_set_splitk(bool on);       // deterministic split-K over 256x256 tiles for under-filled deep-K residual GEMMs
 void gemm_set_persistent_resid(int mask);   // persistent form also for the fp32 (bit 0) / bf16 (bit 1) residual epilogues

@@ -1315,12 +1315,9 @@ int r3g_op_gemm_splitk(const uint16_t* d_a, int64_t lda, const uint16_t* d_w, in
     p.A = d_a; p.lda = lda; p.W = d_w; p.ldw = ldw; p.bias = d_bias; p.C = d_c; p.ldc = ldc; p.gate = d_gate;
     p.M = m_; p.N = n_; p.K = k_; p.epi = epilogue;
     p.split_ws = d_ws; p.split_ws_elems = ws_elems;
-    if (slices) {
-        const int S = gemm_splitk128_factor(m_, n_, k_);
-        *slices = (int64_t)S * m_ * n_ <= ws_elems ? S : 1;
-    }
     hipError_t e = gemm_launch(p, 1, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "r3g_op_gemm_splitk");
+    if (slices) *slices = gemm_last_splitk_slices();      // what the launch actually ran with (not the rule's prediction)
     return R3G_OK;
 }
 

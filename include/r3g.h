@@ -416,7 +416,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * cached), "dit_resid_f16" (1 default: the residual stream of the DiT's de-duplicated CFG path in fp16 -- the reference's own
  * activation type -- | 0: in fp32, rounds 1-3; NOT bit-preserving: 50-step latents at full depth 3.3e-3 against 3.0e-3 from the
  * fp32 oracle, tests/test_cfg1_golden_gpu.py; -21 ms per object), "gelu_pk" (1 default: the GELU epilogues of the GEMMs evaluate x S(x) with S in packed fp16 -- csrc/gemm_common.h: a
- * degree-6 polynomial on v_pk_fma_f16, |error of S| <= 7e-4, +1.2 % on the rel-L2 error behind the bf16 rounding of the output |
+ * degree-6 polynomial on v_pk_fma_f16, |error of S| <= 7.5e-4 as evaluated in fp16 (6.5e-4 tanh / 7.2e-4 erf measured; the fit alone 1.2e-4), +1.2 % on the rel-L2 error behind the bf16 rounding of the output |
  * 0: rounds 3-4's fp32 forms with v_exp_f32 / v_rcp_f32; NOT bit-preserving), attn_generation 9 (opt-in, round 5: the phased 12-wave kernel -- three groups of four
  * waves one phase apart, a wave's matrix phase under the two softmax phases of its SIMD neighbours; bit-identical to generations 2
  * and 6, measured slower: profiles/r05_attention_phases.md), "attn_prio" (generation 9: 0 no s_setprio | 1 its matrix phase at priority 1 | 2 its softmax phases), "attn_stamps" (0 | 1: attn_generation 9 prints the s_memtime ticks of its

@@ -27,7 +27,7 @@ def test_accuracy_and_exact_ends():
     x = np.concatenate([rng.standard_normal(400000).astype(np.float32) * 1.5, np.linspace(-8, 8, 100001).astype(np.float32)])
     for erf, S in ((False, G.S_tanh), (True, G.S_erf)):
         s = G.emulate_s(x, erf).astype(np.float64)
-        assert np.abs(s - S(x.astype(np.float64))).max() <= 8e-4
+        assert np.abs(s - S(x.astype(np.float64))).max() <= 7.5e-4     # the ONE bound: csrc/gemm_common.h, include/r3g.h
         assert (s[x <= -4] == 0).all() and (s[x >= 4] == 1).all() and ((s >= 0) & (s <= 1)).all()
         ref = x.astype(np.float64) * S(x.astype(np.float64))
         got = G.emulate(x, erf).astype(np.float64)
