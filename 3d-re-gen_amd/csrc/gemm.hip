@@ -88,9 +88,23 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int
 // (every kernel but the persistent one); the persistent kernel (round 6) passes 16384: the four groups of a 64-row pass are the
 // wave's OWN 2 KiB staging slices in the four regions of k-tile buffer 1, which is idle between the last k-tile of a tile and
 // the staging of the next tile's k-tile 1 -- and which only this wave's LDS-DMA overwrites, so no workgroup barrier is owed.
+// Round 6: the scratch pointer is an LDS-address-space pointer (and "no scratch" a flag of its own).  As a generic `char*` that could
+// be null, every access went through a flat -> local conversion with a null check and its lane address was rebuilt from scratch --
+// ~14 vector instructions per ds_write, each write in a basic block of its own (hipcc -S), ~500-900 per tile: as much as the
+// arithmetic of the epilogue.  With the address space known the compiler keeps one lane base and folds the rest into offsets.
+#define R3G_LDS __attribute__((address_space(3)))
+typedef R3G_LDS char* LdsP;
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));   // (HIP's uint2 / uint4 are class types: they cannot be copied out of an
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));   // address-space-qualified object; plain vector types can)
+__device__ __forceinline__ uint4 lds_ld4(const R3G_LDS char* a) { const u32x4v v = *reinterpret_cast<const R3G_LDS u32x4v*>(a); return make_uint4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ uint2 lds_ld2(const R3G_LDS char* a) { const u32x2v v = *reinterpret_cast<const R3G_LDS u32x2v*>(a); return make_uint2(v[0], v[1]); }
+__device__ __forceinline__ void lds_st2(R3G_LDS char* a, uint2 v) { *reinterpret_cast<R3G_LDS u32x2v*>(a) = (u32x2v){v.x, v.y}; }
+__device__ __forceinline__ LdsP lds_ptr(char* generic_smem_ptr) { return (LdsP)generic_smem_ptr; }
+
 template <int EPI, int MI, bool SMALLREG, int PI = MI, bool VM0 = false, int SLICE = 2048>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][MI], int m0, int n0, int batch, int wr,
-                                              int wc, int lane, char* lds_wave = nullptr, const f32x4* bias_pre = nullptr) {
+                                              int wc, int lane, LdsP lds_wave = nullptr, bool have_lds = false,
+                                              const f32x4* bias_pre = nullptr) {
     constexpr int WROWS = MI * 16;
     static_assert(MI % PI == 0, "scratch passes");
     static_assert(SLICE == 2048 || ((EPI == EPI_QKV || EPI == EPI_BF16 || EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_BF16_GELU_ERF_LNF) && PI == 4),
@@ -175,16 +189,62 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 return hit;
             };
             const int mw = m0 + wr * WROWS + ip * 16;
-            if (type < 2) {
+            // Round 6: the common case -- the pass's PROWS rows lie inside ONE segment (or there are no segments) and inside M -- is
+            // decided once per pass on the scalar unit; every store address is then base + row * stride, where the general path maps
+            // each row through up to three segments and multiplies 64-bit products per store (~30 vector instructions x 16 stores per
+            // tile: as much as the norm arithmetic itself).  Same addresses, same data.
+            const int mw_u = __builtin_amdgcn_readfirstlane(mw);
+            bool whole = mw_u + PROWS <= p.M;
+            int w_ob = batch;
+            int64_t w_drow = (int64_t)e.dst_row0 + mw_u;
+            if (sg_n > 0) {
+                bool hit = false;
+#pragma unroll
+                for (int sgi = 0; sgi < 3; ++sgi)
+                    if (sgi < sg_n && mw_u >= sg_m0[sgi] && mw_u + PROWS <= sg_m1[sgi]) {
+                        hit = true;
+                        w_ob = sg_b[sgi];
+                        w_drow = (int64_t)sg_d[sgi] + (mw_u - sg_m0[sgi]);
+                    }
+                whole = whole && hit;
+            }
+            if (whole && type < 2) {
+                const int cc = lane & 7;
+                uint16_t* base = (type == 0 ? e.Q + (((int64_t)w_ob * e.heads + head) * e.Lq_pad + w_drow) * 64
+                                            : e.K + (((int64_t)w_ob * e.heads + head) * e.Lk_pad + w_drow) * 64) + cc * 8;
+#pragma unroll
+                for (int t = 0; t < PROWS / 8; ++t) {
+                    const int rr = t * 8 + (lane >> 3);
+                    const uint4 dv = lds_ld4(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
+                    *reinterpret_cast<uint4*>(base + rr * 64) = dv;
+                }
+            } else if (whole && type == 2 && ((w_drow & 15) | ((int64_t)e.Lk_pad & 7)) == 0) {
+                // (PROWS is a multiple of 16 and the segment keeps the rows consecutive: every 16-token group stays whole)
+                constexpr int CPR = PROWS / 8;
+                const int64_t lk = e.Lk_pad;
+                uint16_t* vbase = e.Vt + (((int64_t)w_ob * e.heads + head) * 64) * lk + w_drow;
+#pragma unroll
+                for (int t = 0; t < 64 / (64 / CPR); ++t) {
+                    const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
+                    const int u = ck >> 1, h8 = (ck & 1) * 8;
+                    const int sw = (d >> 2) & (CPR - 1);
+                    const R3G_LDS char* drow_lds = lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2));
+                    const uint2 lo = lds_ld2(drow_lds + (((2 * u) ^ sw) << 4) + h8);
+                    const uint2 hi = lds_ld2(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
+                    *reinterpret_cast<uint4*>(vbase + (int64_t)d * lk + 16 * u + h8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            } else if (type < 2) {
+                // general form (a pass that meets a segment boundary or the end of M): every row mapped on its own.  Rare, so the
+                // loops stay rolled: unrolled, the two general forms were three quarters of the kernel's 35 000 instructions.
                 // 8 tokens x 128 contiguous bytes per store instruction (a token's 64 dims are one cache line)
                 const int cc = lane & 7;
-#pragma unroll
+#pragma unroll 1
                 for (int t = 0; t < PROWS / 8; ++t) {
                     const int rr = t * 8 + (lane >> 3);
                     int ob;
                     int64_t drow;
                     if (!map_row(mw + rr, ob, drow)) continue;
-                    const uint4 dv = *reinterpret_cast<const uint4*>(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
+                    const uint4 dv = lds_ld4(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
                     uint16_t* base = (type == 0 ? e.Q + (((int64_t)ob * e.heads + head) * e.Lq_pad + drow) * 64
                                                 : e.K + (((int64_t)ob * e.heads + head) * e.Lk_pad + drow) * 64);
                     *reinterpret_cast<uint4*>(base + cc * 8) = dv;
@@ -194,14 +254,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 // tokens 16u + 4h + {0..3} and 16u + 8 + 4h + {0..3} = positions 16u + 8h + {0..7}, 16 bytes) when the
                 // whole 16-token group stays together there, otherwise token by token (segment boundaries, ragged ends)
                 constexpr int CPR = PROWS / 8;   // 16-byte chunks per dim row of the LDS image
-#pragma unroll
+#pragma unroll 1
                 for (int t = 0; t < 64 / (64 / CPR); ++t) {
                     const int d = t * (64 / CPR) + lane / CPR, ck = lane % CPR;
                     const int u = ck >> 1, h8 = (ck & 1) * 8;
                     const int sw = (d >> 2) & (CPR - 1);
-                    const char* drow_lds = lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2));
-                    const uint2 lo = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u) ^ sw) << 4) + h8);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
+                    const R3G_LDS char* drow_lds = lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2));
+                    const uint2 lo = lds_ld2(drow_lds + (((2 * u) ^ sw) << 4) + h8);
+                    const uint2 hi = lds_ld2(drow_lds + (((2 * u + 1) ^ sw) << 4) + h8);
                     const int mfirst = mw + 16 * u;
                     int ob0, ob15;
                     int64_t dr0, dr15;
@@ -212,14 +272,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                     } else {
                         const uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
+#pragma unroll 1
                         for (int k = 0; k < 8; ++k) {
                             const int tk = 16 * u + (k < 4 ? (h8 >> 1) + k : 8 + (h8 >> 1) + (k - 4));
                             int ob;
                             int64_t dr;
                             if (map_row(mw + tk, ob, dr))
                                 e.Vt[(((int64_t)ob * e.heads + head) * 64 + d) * lk + vt_key_pos(dr)] =
-                                    (uint16_t)(w4[k >> 1] >> ((k & 1) * 16));
+                                    (uint16_t)((k < 2 ? w4[0] : k < 4 ? w4[1] : k < 6 ? w4[2] : w4[3]) >> ((k & 1) * 16));   // (selects: no dynamic register index)
                         }
                     }
                 }
@@ -229,7 +289,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        // passes of PI row groups: the groups of a pass are staged in the scratch (or stored directly), then the pass leaves
+        // passes of PI row groups: the groups of a pass are staged in the scratch (or stored directly), then the pass leaves.
+        // (round 6: "through the scratch or not" is decided once, outside the unrolled loops)
+        auto all_passes = [&](auto WIDEC) __attribute__((always_inline)) {
+        constexpr bool kWide = decltype(WIDEC)::value;
         static_for<0, MI, PI>([&](auto IPC) __attribute__((always_inline)) {
         constexpr int ip = decltype(IPC)::value;
 #pragma unroll
@@ -242,23 +305,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 v[j] = acc[j][i];
                 if (p.bias) v[j] += bias4[j];
             }
-            if (do_norm) {
+            // sums over the four lanes that share a row (lane ^ 16, lane ^ 32): v_permlane16_swap / v_permlane32_swap on the vector
+            // pipe instead of two ds_bpermute round trips through LDS per row group (round 6; a + b in the same order: same bits)
+            auto row4_sum = [](float x) __attribute__((always_inline)) {
+                typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+                const u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+                const u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+                return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+            };
+            if (do_norm && e.norm == QKN_RMS) {
+                // RMS norm (the DiT's q / k): no mean, no additive term -- round 6 takes them out of the arithmetic instead of
+                // subtracting a zero and adding a zero vector per value (32 of ~100 vector instructions per 16-row group);
+                // (v * r) * w in the general form's order: the same bits
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s2 += v[j][c] * v[j][c];
+                s2 = row4_sum(s2);
+                const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * r * nw4[j];
+            } else if (do_norm) {
                 float mean = 0.f;
                 if (e.norm == QKN_LAYERNORM) {
                     float s1 = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s1 += v[j][0] + v[j][1] + v[j][2] + v[j][3];
-                    s1 += __shfl_xor(s1, 16, 64);
-                    s1 += __shfl_xor(s1, 32, 64);
-                    mean = s1 * (1.f / 64.f);
+                    mean = row4_sum(s1) * (1.f / 64.f);
                 }
                 float s2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { const float d = v[j][c] - mean; s2 += d * d; }
-                s2 += __shfl_xor(s2, 16, 64);
-                s2 += __shfl_xor(s2, 32, 64);
+                s2 = row4_sum(s2);
                 const float r = rsqrtf(s2 * (1.f / 64.f) + e.eps);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) * r * nw4[j] + nb4[j];
@@ -267,7 +349,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= e.q_scale;
             }
-            if (lds_wave != nullptr) {
+            if constexpr (kWide) {
                 // stage the normalised tile in the wave's LDS scratch: Q / K as [token][64 dims] (16-byte chunks
                 // swizzled by the token), V as [dim][token] (chunks of 8 tokens swizzled by the dim group)
                 const int r = ii * 16 + (lane & 15), q = lane >> 4;
@@ -278,7 +360,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         pk.x = pack_bf16(v[j][0], v[j][1]);
                         pk.y = pack_bf16(v[j][2], v[j][3]);
                         const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
-                        *reinterpret_cast<uint2*>(lds_wave + roff(r) + chunk * 16 + (q & 1) * 8) = pk;
+                        lds_st2(lds_wave + roff(r) + chunk * 16 + (q & 1) * 8, pk);
                     }
                 } else {
 #pragma unroll
@@ -287,7 +369,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         for (int c = 0; c < 4; ++c) {
                             const int d = j * 16 + q * 4 + c;
                             const int chunk = (r >> 3) ^ ((d >> 2) & (PROWS / 8 - 1));
-                            *reinterpret_cast<uint16_t*>(lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2)) + chunk * 16 + (r & 7) * 2) =
+                            *reinterpret_cast<R3G_LDS uint16_t*>(lds_wave + (PROWS * 2 == 128 ? roff(d) : d * (PROWS * 2)) + chunk * 16 + (r & 7) * 2) =
                                 (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
                         }
                 }
@@ -327,8 +409,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         base[(int64_t)(j * 16 + dbase + c) * e.Lk_pad] = (uint16_t)(pack_bf16(v[j][c], 0.f) & 0xFFFFu);
             }
         }
-        if (lds_wave != nullptr) flush_pass(ip);
+        if constexpr (kWide) flush_pass(ip);
         });
+        };
+        if (have_lds) all_passes(std::true_type{});
+        else all_passes(std::false_type{});
         return;
     }
     // epilogue: lane holds, for sub-tile (j,i): row m = .. + (lane&15), cols n = .. + (lane>>4)*4 + {0..3}.
@@ -341,7 +426,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
         // e4m3 output with a static scale: the operand of the fp8 GEMM that follows (the MLP hidden of the geo decoder)
         uint8_t* C8 = reinterpret_cast<uint8_t*>(p.C) + (int64_t)batch * p.strideC;
         const float inv = p.out_inv_scale;
-        const bool wide = lds_wave != nullptr && PI == MI && (p.N & 15) == 0 && (p.ldc & 15) == 0 && (p.strideC & 15) == 0 &&
+        const bool wide = have_lds && PI == MI && (p.N & 15) == 0 && (p.ldc & 15) == 0 && (p.strideC & 15) == 0 &&
                           (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -355,7 +440,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
                 const int r = i * 16 + (lane & 15), m = mrow + i * 16;
-                if (wide) *reinterpret_cast<uint32_t*>(lds_wave + r * 64 + ((j ^ (r & 3)) << 4) + ((lane >> 4) << 2)) = (uint32_t)w;
+                if (wide) *reinterpret_cast<R3G_LDS uint32_t*>(lds_wave + r * 64 + ((j ^ (r & 3)) << 4) + ((lane >> 4) << 2)) = (uint32_t)w;
                 else if (n < p.N && m < p.M) *reinterpret_cast<uint32_t*>(C8 + (int64_t)m * p.ldc + n) = (uint32_t)w;
             }
         }
@@ -367,7 +452,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             for (int t = 0; t < WROWS / 16; ++t) {       // 16 rows x 64 contiguous bytes per store instruction
                 const int rr = t * 16 + (lane >> 2);
                 const int m = m0 + wr * WROWS + rr;
-                const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + rr * 64 + ((cc ^ (rr & 3)) << 4));
+                const uint4 d = lds_ld4(lds_wave + rr * 64 + ((cc ^ (rr & 3)) << 4));
                 if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C8 + (int64_t)m * p.ldc + n) = d;
             }
         }
@@ -390,7 +475,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             if (p.bias) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + nbc);
             if (gate) gj[j] = *reinterpret_cast<const f32x4*>(gate + nbc);
         }
-        const bool wide = lds_wave != nullptr && PI >= 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0 &&
+        const bool wide = have_lds && PI >= 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.strideC & 7) == 0 &&
                           (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(XR) & 15) == 0;
         if (wide) {
             // passes of RP rows x 64 columns of fp32 through the wave's scratch (256-byte rows, 16-byte chunks swizzled by
@@ -422,7 +507,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     for (int ii = 0; ii < GP; ++ii) {
                         const int r = ii * 16 + (lane & 15);
                         const int chunk = (j * 4 + (lane >> 4)) ^ (r & 15);
-                        *reinterpret_cast<f32x4*>(lds_wave + r * 256 + chunk * 16) = gj[j] * (acc[j][ip + ii] + bj[j]);
+                        *reinterpret_cast<R3G_LDS f32x4*>(lds_wave + r * 256 + chunk * 16) = gj[j] * (acc[j][ip + ii] + bj[j]);
                     }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -430,8 +515,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 for (int t = 0; t < RP / 8; ++t) {
                     const int rr = t * 8 + (lane >> 3);
                     const int m = m0 + wr * WROWS + ip * 16 + rr;
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(lds_wave + rr * 256 + (((2 * cc) ^ (rr & 15)) << 4));
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(lds_wave + rr * 256 + (((2 * cc + 1) ^ (rr & 15)) << 4));
+                    const f32x4 d0 = *reinterpret_cast<const R3G_LDS f32x4*>(lds_wave + rr * 256 + (((2 * cc) ^ (rr & 15)) << 4));
+                    const f32x4 d1 = *reinterpret_cast<const R3G_LDS f32x4*>(lds_wave + rr * 256 + (((2 * cc + 1) ^ (rr & 15)) << 4));
                     const uint32_t o[4] = {old[t].x, old[t].y, old[t].z, old[t].w};
                     uint32_t q[4];
 #pragma unroll
@@ -502,7 +587,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     }
     if constexpr (EPI == EPI_RESID_F32) {
         float* X = reinterpret_cast<float*>(p.C) + (int64_t)batch * p.strideC;
-        const bool wide = lds_wave != nullptr && (p.ldc & 3) == 0 && (p.strideC & 3) == 0 &&
+        const bool wide = have_lds && (p.ldc & 3) == 0 && (p.strideC & 3) == 0 &&
                           (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
         if (wide) {
             // Read-modify-write through a wave-private LDS transpose, 32 columns (two 16-column groups) per pass: the
@@ -530,7 +615,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         for (int ii = 0; ii < PI; ++ii) {
                             const int r = ii * 16 + (lane & 15);
                             const int chunk = (jj * 4 + (lane >> 4)) ^ (r & 7);
-                            *reinterpret_cast<f32x4*>(lds_wave + r * 128 + chunk * 16) = gj[jj] * (acc[2 * jp + jj][ip + ii] + bj[jj]);
+                            *reinterpret_cast<R3G_LDS f32x4*>(lds_wave + r * 128 + chunk * 16) = gj[jj] * (acc[2 * jp + jj][ip + ii] + bj[jj]);
                         }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -548,7 +633,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                         for (int tt = 0; tt < 4; ++tt) {
                             const int rr = (t0 + tt) * 8 + (lane >> 3);
                             const int m = m0 + wr * WROWS + ip * 16 + rr;
-                            const f32x4 d = *reinterpret_cast<const f32x4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                            const f32x4 d = *reinterpret_cast<const R3G_LDS f32x4*>(lds_wave + rr * 128 + ((cc ^ (rr & 7)) << 4));
                             if (n < p.N && m < p.M) *reinterpret_cast<f32x4*>(X + (int64_t)m * p.ldc + n) = old[tt] + d;
                         }
                     }
@@ -599,7 +684,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     } else {
         // bf16 outputs go through a wave-private LDS transpose when the layout allows 16-byte stores: a store
         // instruction then writes 8 rows x 128 contiguous bytes (whole cache lines) instead of 16 rows x 32 bytes
-        const bool wide = EPI != EPI_F32 && lds_wave != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
+        const bool wide = EPI != EPI_F32 && have_lds && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
                           (p.strideC & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
         if (VM0 && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // LNF (round 6): the LayerNorm of A's rows folded into this GEMM -- v = rstd[m] (acc - mean[m] c1[n]) + c2[n] (c2 = p.bias)
@@ -619,50 +704,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             }
         }
         // PK: the GELU epilogues in packed fp16 (gemm_common.h; run-time option "gelu_pk", one wave-uniform branch per tile)
-        auto body = [&](auto PKC) __attribute__((always_inline)) {
+        // WIDEC: the LDS-transposed form, decided ONCE per tile (round 6: as a run-time test inside the unrolled loops it cut the
+        // epilogue into one basic block per LDS write)
+        auto body = [&](auto PKC, auto WIDEC) __attribute__((always_inline)) {
         constexpr bool PK = decltype(PKC)::value;
+        constexpr bool kWide = decltype(WIDEC)::value && EPI != EPI_F32;
+        static_assert(MI % 2 == 0 && PI % 2 == 0, "register groups are taken two at a time");
+        // two register groups (rows i, i + 1 of column group j) at a time: with the packed-fp16 GELU their four pair chains run in
+        // lockstep (gemm_common.h gelu_pk_sn)
+        auto value2 = [&](int j, int i, f32x4 (&v)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ip = 0; ip < MI; ip += PI) {
+            for (int h = 0; h < 2; ++h) {
+                v[h] = acc[j][i + h] + biasv[j];
+                if constexpr (LNF) v[h] = st[i + h][1] * (acc[j][i + h] - st[i + h][0] * c1v[j]) + biasv[j];
+            }
+            constexpr bool kTanh = EPI == EPI_BF16_GELU_TANH, kErf = EPI == EPI_BF16_GELU_ERF || LNF;
+            if constexpr ((kTanh || kErf) && PK) {
+                gelu_pk4n<kErf, 2>(v);
+            } else if constexpr (kTanh) {
+                v[0] = gelu_tanh4<false>(v[0]); v[1] = gelu_tanh4<false>(v[1]);
+            } else if constexpr (kErf) {
+                v[0] = gelu_erf4<false>(v[0]); v[1] = gelu_erf4<false>(v[1]);
+            }
+        };
+        if constexpr (kWide) {
+            // lane parts of the scratch addresses: row (lane & 15) of a 16-row group, 8-byte half (q & 1) of chunk (2 j + (q >> 1)) ^ (row & 7)
+            const int q = lane >> 4, l7 = lane & 7;
+            const LdsP wbase = lds_wave + (lane & 15) * 128 + (q & 1) * 8;
+            int wch[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) wch[j] = ((2 * j + (q >> 1)) ^ l7) << 4;
+            const int cc = lane & 7;
+            const LdsP rbase = lds_wave + (lane >> 3) * 128 + ((cc ^ ((lane >> 3) & 7)) << 4);   // row t * 8 + (lane >> 3): (rr & 7) == (lane >> 3)
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
+            const int n = n0 + wc * 64 + cc * 8;
 #pragma unroll
-                for (int ii = 0; ii < PI; ++ii) {
-                    const int i = ip + ii;
-                    const int n = ncol + j * 16, m = mrow + i * 16;
-                    f32x4 v = acc[j][i] + biasv[j];
-                    if constexpr (LNF) v = st[i][1] * (acc[j][i] - st[i][0] * c1v[j]) + biasv[j];
-                    if (EPI == EPI_BF16_GELU_TANH) v = gelu_tanh4<PK>(v);
-                    else if (EPI == EPI_BF16_GELU_ERF || LNF) v = gelu_erf4<PK>(v);
-                    if (EPI != EPI_F32 && wide) {
-                        uint2 pk;
-                        pk.x = pack_bf16(v[0], v[1]);
-                        pk.y = pack_bf16(v[2], v[3]);
-                        const int r = ii * 16 + (lane & 15), q = lane >> 4;
-                        const int chunk = (2 * j + (q >> 1)) ^ (r & 7);
-                        *reinterpret_cast<uint2*>(lds_wave + roff(r) + chunk * 16 + (q & 1) * 8) = pk;
-                    } else if (n < p.N && m < p.M) {
-                        const int64_t off = cbase + (int64_t)m * p.ldc + n;
-                        if (EPI == EPI_F32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
-                        } else {
+            for (int ip = 0; ip < MI; ip += PI) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < PI; ii += 2) {
+                        f32x4 v[2];
+                        value2(j, ip + ii, v);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
                             uint2 pk;
-                            pk.x = pack_bf16(v[0], v[1]);
-                            pk.y = pack_bf16(v[2], v[3]);
-                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                            pk.x = pack_bf16(v[h][0], v[h][1]);
+                            pk.y = pack_bf16(v[h][2], v[h][3]);
+                            lds_st2(wbase + roff((ii + h) * 16) + wch[j], pk);
                         }
                     }
-                }
-            if (EPI != EPI_F32 && wide) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
-                const int cc = lane & 7, n = n0 + wc * 64 + cc * 8;
                 if (VM0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int t = 0; t < PI * 2; ++t) {
-                    const int rr = t * 8 + (lane >> 3);
-                    const int m = m0 + wr * WROWS + ip * 16 + rr;
-                    const uint4 d = *reinterpret_cast<const uint4*>(lds_wave + roff(rr) + ((cc ^ (rr & 7)) << 4));
+                    const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
+                    const uint4 d = lds_ld4(rbase + roff(t * 8));
                     if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
                 }
                 if (PI != MI) {
@@ -670,13 +768,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < MI; i2 += 2) {
+                    f32x4 v2[2];
+                    value2(j, i2, v2);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = i2 + h;
+                        const int n = ncol + j * 16, m = mrow + i * 16;
+                        const f32x4 v = v2[h];
+                        if (n < p.N && m < p.M) {
+                            const int64_t off = cbase + (int64_t)m * p.ldc + n;
+                            if (EPI == EPI_F32) {
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+                            } else {
+                                uint2 pk;
+                                pk.x = pack_bf16(v[0], v[1]);
+                                pk.y = pack_bf16(v[2], v[3]);
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + off) = pk;
+                            }
+                        }
+                    }
+                }
         }
         };
+        auto body_w = [&](auto PKC) __attribute__((always_inline)) {
+            if (wide) body(PKC, std::true_type{});
+            else body(PKC, std::false_type{});
+        };
         if constexpr (EPI == EPI_BF16_GELU_TANH || EPI == EPI_BF16_GELU_ERF || EPI == EPI_BF16_GELU_ERF_LNF) {
-            if (p.gelu_pk) body(std::true_type{});
-            else body(std::false_type{});
+            if (p.gelu_pk) body_w(std::true_type{});
+            else body_w(std::false_type{});
         } else {
-            body(std::false_type{});
+            body_w(std::false_type{});
         }
     }
 }
@@ -791,8 +918,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs pa, GemmArgs pb)
         __syncthreads();
     }
 
-    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane,
-                                       p.wide_epilogue ? smem + wid * (WROWS * 128) : nullptr);
+    gemm_epilogue<EPI, MI, (BIG == 1)>(p, acc, m0, n0, batch, wr, wc, lane, lds_ptr(smem + wid * (WROWS * 128)), p.wide_epilogue != 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -906,7 +1032,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    gemm_epilogue<EPI, MI, false>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (WROWS * 128) : nullptr);
+    gemm_epilogue<EPI, MI, false>(p, acc, m0, n0, batch, wr, wc, lane, lds_ptr(smem + wid * (WROWS * 128)), p.wide_epilogue != 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1280,7 +1406,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs pa, GemmArgs pb, fl
             }
         }
     }
-    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
+    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, lds_ptr(smem + wid * (128 * 128)), p.wide_epilogue != 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1513,7 +1639,7 @@ __global__ __launch_bounds__(512) void gemm8f_kernel(GemmArgs pa, GemmArgs pb, c
 #pragma unroll
             for (int i = 0; i < MI; ++i) acc[j][i] *= swv[j] * sav[i];
     }
-    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, p.wide_epilogue ? smem + wid * (128 * 128) : nullptr);
+    gemm_epilogue<EPI, MI, true>(p, acc, m0, n0, batch, wr, wc, lane, lds_ptr(smem + wid * (128 * 128)), p.wide_epilogue != 0);
 }
 
 
@@ -1801,11 +1927,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
                 constexpr bool kPre = epi == EPI_BF16 || epi == EPI_BF16_GELU_TANH || epi == EPI_BF16_GELU_ERF || epi == EPI_BF16_GELU_ERF_LNF;
                 constexpr bool kSl = SLICED && (kPre || epi == EPI_QKV);
                 if constexpr (kSl)
+                    // (the launcher takes the SLICED instantiation only for launches with the wide epilogue: a literal `true` lets
+                    // the compiler drop the direct-store copy of the fused-QKV epilogue from this kernel)
                     gemm_epilogue<epi, MI, true, 4, false, HALF>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
-                                                                 pp.wide_epilogue ? smem + BUF + wid * 2048 : nullptr, kPre ? bias_pre : nullptr);
+                                                                 lds_ptr(smem + BUF + wid * 2048), true, kPre ? bias_pre : nullptr);
                 else
                     gemm_epilogue<epi, MI, true, 2, false>(pp, acc, done.m0, done.n0, done.batch, wr, wc, lane_e,
-                                                           pp.wide_epilogue ? smem + 2 * BUF + wid * 4096 : nullptr, kPre ? bias_pre : nullptr);
+                                                           lds_ptr(smem + 2 * BUF + wid * 4096), pp.wide_epilogue != 0, kPre ? bias_pre : nullptr);
             };
             if constexpr (EPI2 != EPI) {
                 if (done.second) run(std::integral_constant<int, EPI2>{});

@@ -82,8 +82,65 @@ __device__ __forceinline__ h16x2 gelu_pk_s(float x0, float x1) {
     return h16_clamp01(t * acc + h16_splat(0.5f));                  // S in [0, 1]
 }
 
+// The same for NP pairs IN LOCKSTEP (round 6): Horner's rule is a chain of dependent packed instructions, and on gfx950 a packed
+// fp16 instruction that reads the result of the one before it needs a wait state -- hipcc scheduled one pair's chain after the
+// other with an s_nop behind every link (301 s_nop among the 846 instructions of a 64-row GELU pass).  Step-outer, pair-inner: the
+// neighbours' links fill each other's wait states.  The arithmetic per pair is gelu_pk_s's, instruction for instruction: same bits.
+template <bool ERF, int NP>
+__device__ __forceinline__ void gelu_pk_sn(const float (&x)[2 * NP], h16x2 (&s)[NP]) {
+    constexpr float c0 = (ERF ? 0.7041015625f : 0.7041015625f) * 0.25f;
+    constexpr float c1 = (ERF ? -0.33837890625f : -0.3388671875f) * 0.25f;
+    constexpr float c2 = (ERF ? 0.2225341796875f : 0.22216796875f) * 0.25f;
+    constexpr float c3 = (ERF ? -0.1378173828125f : -0.13525390625f) * 0.25f;
+    constexpr float c4 = (ERF ? 0.0916748046875f : 0.08990478515625f) * 0.25f;
+    constexpr float c5 = (ERF ? -0.07086181640625f : -0.07281494140625f) * 0.25f;
+    constexpr float c6 = (ERF ? 0.0289154052734375f : 0.0306396484375f) * 0.25f;
+    constexpr float cs[6] = {c5, c4, c3, c2, c1, c0};
+    h16x2 t[NP], z[NP], a[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) t[p] = (h16x2){(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) z[p] = t[p] * h16_splat(0.0625f);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) z[p] = h16_clamp01(t[p] * z[p]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) z[p] = z[p] * h16_splat(2.f) + h16_splat(-1.f);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = h16_splat(c6) * z[p] + h16_splat(c5);
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] * z[p] + h16_splat(cs[k]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = h16_clamp01(t[p] * a[p] + h16_splat(0.5f));
+}
+
 // x * S for four values in fp32: v_fma_mix_f32 reads S as the low / high fp16 half of its pair (no conversion instruction; the
 // compiler does not select the instruction from C++, hence the asm -- ONE statement, so that it pads at most once around it)
+__device__ __forceinline__ f32x4 gelu_pk_mix(f32x4 v, h16x2 s01, h16x2 s23) {
+    float g0, g1, g2, g3;
+    asm("v_fma_mix_f32 %0, %4, %8, 0 op_sel_hi:[0,1,0]\n\t"
+        "v_fma_mix_f32 %1, %5, %8, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+        "v_fma_mix_f32 %2, %6, %9, 0 op_sel_hi:[0,1,0]\n\t"
+        "v_fma_mix_f32 %3, %7, %9, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+        : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s01), "v"(s23));
+    return (f32x4){g0, g1, g2, g3};
+}
+// NV register groups at once: 2 NV pair chains in lockstep
+template <bool ERF, int NV>
+__device__ __forceinline__ void gelu_pk4n(f32x4 (&v)[NV]) {
+    float x[4 * NV];
+    h16x2 s[2 * NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[4 * i + c] = v[i][c];
+    gelu_pk_sn<ERF, 2 * NV>(x, s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = gelu_pk_mix(v[i], s[2 * i], s[2 * i + 1]);
+}
+
 template <bool ERF>
 __device__ __forceinline__ f32x4 gelu_pk4(f32x4 v) {
     const h16x2 s01 = gelu_pk_s<ERF>(v[0], v[1]), s23 = gelu_pk_s<ERF>(v[2], v[3]);

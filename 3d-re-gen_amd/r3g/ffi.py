@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libr3g.so")
+# (R3G_LIBRARY: a measurement hook -- `tools/r06_gpu.sh ablib` times two BUILDS of the library against each other on one box)
+LIB_PATH = os.environ.get("R3G_LIBRARY") or os.path.join(_PKG, "libr3g.so")
 
 R3G_ERR_LEVEL_RANGE = -10
 R3G_ERR_NO_SURFACE = -11

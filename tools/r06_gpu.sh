@@ -58,6 +58,27 @@ PY
         done
     done
     ;;
+ablib)
+    # two BUILDS of the library against each other on one box: tools/r06_gpu.sh ablib <other .so> [steps] [warmup]  (A = the other, B = this tree's)
+    OTHER="$2"; K="${3:-8}"; W="${4:-4}"
+    for i in 1 2; do
+        for side in a b; do
+            if [ $side = a ]; then export R3G_LIBRARY="$(pwd)/$OTHER"; else unset R3G_LIBRARY; fi
+            timeout 300 python bench.py --gpus 1 --steps $K --warmup $W --no-cpu-baseline > $O/r06_ablib_${side}${i}.json 2> $O/r06_ablib_${side}${i}.err
+            python - <<PY
+import json
+try:
+    d=json.loads(open("$O/r06_ablib_${side}${i}.json").read().strip().splitlines()[-1])
+    f = d.get("roofline", {}).get("families_ms_per_object", {})
+    print("ABLIB ${side}${i} lib='${R3G_LIBRARY:-this tree}'", round(d["value"], 4), "obj/s", round(d["ms_per_step"], 1), "ms", {k: v for k, v in f.items() if v >= 1.0}, d.get("mc_parity"))
+except Exception as e:
+    print("ABLIB ${side}${i} FAILED", e)
+PY
+            tail -2 $O/r06_ablib_${side}${i}.err | cut -c1-300
+        done
+    done
+    unset R3G_LIBRARY
+    ;;
 mc)
     R=$(pwd)
     for f in blob noise; do
