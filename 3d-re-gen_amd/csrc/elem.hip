@@ -65,11 +65,16 @@ __device__ __forceinline__ float4 row4_cvt(const Half4Raw& h) {
 //   workgroup of 4 rows lives ~6 us however little it does (dispatch, kernarg fetch, exit), which at 131 072 rows per
 //   launch is as long as its memory time; 4 x RPW rows per workgroup amortise it.
 // The arithmetic per row (element -> lane map, order of every sum) is the same in all instantiations.
-template <int XBF16, int NV, int RPW>
+// MODE (round 6): which optional terms a launch has, known at compile time for the two combinations the path is made of -- 1: affine
+// (w and b; VAE / DINOv2 / geo decoder), 2: adaLN modulation (scale and shift, no affine; every DiT LayerNorm); -1: decided at run time
+// (anything else, and the fp8 output).  The run-time form tests four pointers per register group inside its unrolled loops: 66
+// v_cndmask and 19 branches in 686 instructions per row.  Same operations in the same order: bit-identical (tests/test_model_gpu.py).
+template <int XBF16, int NV, int RPW, int MODE = -1>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     constexpr int NVC = NV ? NV : LN_MAX_V4;
     const int lane = threadIdx.x & 63;
     const int nv = NV ? NV : (p.C >> 8);
+    const bool has_w = MODE < 0 ? p.w != nullptr : (MODE & 1) != 0, has_b = MODE < 0 ? p.b != nullptr : (MODE & 1) != 0;
     typedef typename Row4Raw<XBF16>::type Raw;
     float4 v[NVC];
     Raw vr[NVC];
@@ -85,12 +90,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     load(row);
     // the affine weights do not depend on the row: fetched once per wave
     float4 wv[NVC], bv[NVC];
-    if (p.w) {
+    if (has_w) {
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
             if (NV || i < nv) wv[i] = *reinterpret_cast<const float4*>(p.w + (i * 64 + lane) * 4);
     }
-    if (p.b) {
+    if (has_b) {
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
             if (NV || i < nv) bv[i] = *reinterpret_cast<const float4*>(p.b + (i * 64 + lane) * 4);
@@ -105,16 +110,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             if (NV || i < nv) v[i] = row4_cvt(vr[i]);
         const int batch = row / p.rows_per_batch, lrow = row - batch * p.rows_per_batch;
         const bool seg2 = row >= p.seg2_row0 && row < p.seg2_row1;   // wave-uniform (one row per wave at a time)
-        const float* sc = seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
-        const float* sh = seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
+        const float* sc = MODE >= 0 && !(MODE & 2) ? nullptr : seg2 ? p.scale2 : (p.scale ? p.scale + (int64_t)batch * p.mod_stride : nullptr);
+        const float* sh = MODE >= 0 && !(MODE & 2) ? nullptr : seg2 ? p.shift2 : (p.shift ? p.shift + (int64_t)batch * p.mod_stride : nullptr);
+        const bool has_sc = MODE < 0 ? sc != nullptr : (MODE & 2) != 0, has_sh = MODE < 0 ? sh != nullptr : (MODE & 2) != 0;
         // the modulation vectors are 8 bytes per element against the row's 2-4: a wave's consecutive rows nearly always
         // share them (same object, same segment), so they stay in registers until the pointer changes (wave-uniform)
-        if (sc && sc != sc_held) {
+        if (has_sc && sc != sc_held) {
 #pragma unroll
             for (int i = 0; i < NVC; ++i)
                 if (NV || i < nv) av[i] = *reinterpret_cast<const float4*>(sc + (i * 64 + lane) * 4);
         }
-        if (sh && sh != sh_held) {
+        if (has_sh && sh != sh_held) {
 #pragma unroll
             for (int i = 0; i < NVC; ++i)
                 if (NV || i < nv) hv[i] = *reinterpret_cast<const float4*>(sh + (i * 64 + lane) * 4);
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             }
         const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
         uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
-        const bool to_fp8 = p.y8 != nullptr;      // wave-uniform
+        const bool to_fp8 = MODE < 0 && p.y8 != nullptr;      // wave-uniform
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
@@ -145,13 +151,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
                 // every product and sum rounded on its own (__fmul_rn / __fadd_rn are never contracted): whether the
                 // compiler fuses `o * w + b` depends on the control flow around it, which differs between instantiations
-                if (p.w) { o[0] = __fmul_rn(o[0], wv[i].x); o[1] = __fmul_rn(o[1], wv[i].y); o[2] = __fmul_rn(o[2], wv[i].z); o[3] = __fmul_rn(o[3], wv[i].w); }
-                if (p.b) { o[0] = __fadd_rn(o[0], bv[i].x); o[1] = __fadd_rn(o[1], bv[i].y); o[2] = __fadd_rn(o[2], bv[i].z); o[3] = __fadd_rn(o[3], bv[i].w); }
-                if (sc) {
+                if (has_w) { o[0] = __fmul_rn(o[0], wv[i].x); o[1] = __fmul_rn(o[1], wv[i].y); o[2] = __fmul_rn(o[2], wv[i].z); o[3] = __fmul_rn(o[3], wv[i].w); }
+                if (has_b) { o[0] = __fadd_rn(o[0], bv[i].x); o[1] = __fadd_rn(o[1], bv[i].y); o[2] = __fadd_rn(o[2], bv[i].z); o[3] = __fadd_rn(o[3], bv[i].w); }
+                if (has_sc) {
                     o[0] = __fmul_rn(o[0], __fadd_rn(1.f, av[i].x)); o[1] = __fmul_rn(o[1], __fadd_rn(1.f, av[i].y));
                     o[2] = __fmul_rn(o[2], __fadd_rn(1.f, av[i].z)); o[3] = __fmul_rn(o[3], __fadd_rn(1.f, av[i].w));
                 }
-                if (sh) { o[0] = __fadd_rn(o[0], hv[i].x); o[1] = __fadd_rn(o[1], hv[i].y); o[2] = __fadd_rn(o[2], hv[i].z); o[3] = __fadd_rn(o[3], hv[i].w); }
+                if (has_sh) { o[0] = __fadd_rn(o[0], hv[i].x); o[1] = __fadd_rn(o[1], hv[i].y); o[2] = __fadd_rn(o[2], hv[i].z); o[3] = __fadd_rn(o[3], hv[i].w); }
                 if (to_fp8) {   // keep the finished values (the row's maximum decides their scale), write below
                     v[i] = make_float4(o[0], o[1], o[2], o[3]);
                     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
@@ -582,7 +588,16 @@ inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
     {                                                                                                                      \
         const bool r4 = ln_rows_per_wave(p.rows) == 4;                                                                     \
         const dim3 g1((p.rows + 3) / 4), g4((p.rows + 15) / 16), blk(256);                                                 \
-        if (p.C == 1024 && g_ln_fixed) {                                                                                   \
+        /* the two combinations the path is made of, with their optional terms known at compile time (MODE) */            \
+        const bool m_aff = g_ln_modes && p.w && p.b && !p.scale && !p.shift && !p.scale2 && !p.shift2 && !p.y8;            \
+        const bool m_mod = g_ln_modes && !p.w && !p.b && p.scale && p.shift && !p.y8 && (p.seg2_row1 <= p.seg2_row0 || (p.scale2 && p.shift2)); \
+        if (p.C == 1024 && g_ln_fixed && m_mod) {                                                                          \
+            if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 4, 4, 2>), g4, blk, 0, s, p);                                 \
+            else hipLaunchKernelGGL((layernorm_kernel<XB, 4, 1, 2>), g1, blk, 0, s, p);                                    \
+        } else if (p.C == 1024 && g_ln_fixed && m_aff) {                                                                   \
+            if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 4, 4, 1>), g4, blk, 0, s, p);                                 \
+            else hipLaunchKernelGGL((layernorm_kernel<XB, 4, 1, 1>), g1, blk, 0, s, p);                                    \
+        } else if (p.C == 1024 && g_ln_fixed) {                                                                            \
             if (r4) hipLaunchKernelGGL((layernorm_kernel<XB, 4, 4>), g4, blk, 0, s, p);                                    \
             else hipLaunchKernelGGL((layernorm_kernel<XB, 4, 1>), g1, blk, 0, s, p);                                       \
         } else if (p.C == 1536 && g_ln_fixed) {                                                                            \
@@ -596,6 +611,8 @@ inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 // rows per wave of the row-in-registers kernels: 4 when that still leaves >= 4096 workgroups (two per workgroup slot of
 // the device), otherwise 1 (the DiT's 7 552-row launches need every wave they can get).  g_ln_rows: 0 automatic | 1 | 4.
 static int g_ln_rows = 0;
+static bool g_ln_modes = true;   // option "ln_modes" (round 6): compile-time MODE instantiations for the affine-only / modulation-only launches
+void ln_set_modes(bool on) { g_ln_modes = on; }
 static bool g_ln_fixed = true;   // compile-time element counts for C = 1024 / 1536 (0: round 2's run-time count everywhere)
 void ln_set_fixed_count(bool on) { g_ln_fixed = on; }
 void ln_set_rows_per_wave(int rows) { g_ln_rows = rows == 1 || rows == 4 ? rows : 0; }

@@ -491,15 +491,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 gw0 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc);
                 gw1 = *reinterpret_cast<const f32x4*>(p.lnd_gw + nc + 4);
             }
+            // (round 6) the wave's block inside the matrix: unclamped loads, unpredicated stores, one address product per tile
+            const bool full = m0 + wr * WROWS + WROWS <= p.M && n0 + wc * 64 + 64 <= p.N;      // wave-uniform
+            const int64_t row0 = (int64_t)(m0 + wr * WROWS + (lane >> 3)) * p.ldc + n, step8 = 8 * (int64_t)p.ldc;
 #pragma unroll
             for (int ip = 0; ip < MI; ip += GP) {
                 uint4 old[RP / 8];
+                if (full) {
 #pragma unroll
-                for (int t = 0; t < RP / 8; ++t) {
-                    const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
-                    const int mc = m < p.M ? m : p.M - 1;
-                    const int nc = n < p.N ? n : p.N - 8;
-                    old[t] = *reinterpret_cast<const uint4*>(XR + (int64_t)mc * p.ldc + nc);
+                    for (int t = 0; t < RP / 8; ++t)
+                        old[t] = *reinterpret_cast<const uint4*>(XR + row0 + (int64_t)(ip * 2 + t) * step8);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RP / 8; ++t) {
+                        const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
+                        const int mc = m < p.M ? m : p.M - 1;
+                        const int nc = n < p.N ? n : p.N - 8;
+                        old[t] = *reinterpret_cast<const uint4*>(XR + (int64_t)mc * p.ldc + nc);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -511,6 +520,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                     }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                auto rows_out = [&](auto FULLC) __attribute__((always_inline)) {
+                constexpr bool kFull = decltype(FULLC)::value;
 #pragma unroll
                 for (int t = 0; t < RP / 8; ++t) {
                     const int rr = t * 8 + (lane >> 3);
@@ -554,9 +565,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                             *reinterpret_cast<f32x4*>(p.lnd_part + ((int64_t)m * (p.N >> 6) + ((n0 >> 6) + wc)) * 4) = (f32x4){s1, m2, s3, 0.f};
                     }
                     if constexpr (!LND || ST) {
-                        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
+                        if constexpr (kFull) *reinterpret_cast<uint4*>(X + row0 + (int64_t)(ip * 2 + t) * step8) = make_uint4(q[0], q[1], q[2], q[3]);
+                        else if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(X + (int64_t)m * p.ldc + n) = make_uint4(q[0], q[1], q[2], q[3]);
                     }
                 }
+                };
+                if (full) rows_out(std::true_type{});
+                else rows_out(std::false_type{});
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -738,6 +753,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
             const LdsP rbase = lds_wave + (lane >> 3) * 128 + ((cc ^ ((lane >> 3) & 7)) << 4);   // row t * 8 + (lane >> 3): (rr & 7) == (lane >> 3)
             uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + cbase;
             const int n = n0 + wc * 64 + cc * 8;
+            const bool full = m0 + wr * WROWS + WROWS <= p.M && n0 + wc * 64 + 64 <= p.N;      // wave-uniform
+            uint16_t* const crow = C + (int64_t)(m0 + wr * WROWS + (lane >> 3)) * p.ldc + n;    // row (lane >> 3) of the wave's block
+            const int64_t step8 = 8 * (int64_t)p.ldc;
 #pragma unroll
             for (int ip = 0; ip < MI; ip += PI) {
 #pragma unroll
@@ -757,11 +775,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (VM0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (full) {      // the wave's 128 x 64 block lies inside the matrix: no predicates, one address product per tile
 #pragma unroll
-                for (int t = 0; t < PI * 2; ++t) {
-                    const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
-                    const uint4 d = lds_ld4(rbase + roff(t * 8));
-                    if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
+                    for (int t = 0; t < PI * 2; ++t)
+                        *reinterpret_cast<uint4*>(crow + (int64_t)(ip * 2 + t) * step8) = lds_ld4(rbase + roff(t * 8));
+                } else {
+#pragma unroll
+                    for (int t = 0; t < PI * 2; ++t) {
+                        const int m = m0 + wr * WROWS + ip * 16 + t * 8 + (lane >> 3);
+                        const uint4 d = lds_ld4(rbase + roff(t * 8));
+                        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + n) = d;
+                    }
                 }
                 if (PI != MI) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

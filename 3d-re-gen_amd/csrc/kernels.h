@@ -175,6 +175,7 @@ void attn_set_prio(int v);            // generation 9: 0 no s_setprio | 1 matrix
 void attn_set_stamps(int on);         // generation 9: print per-phase s_memtime sums of every launch to stderr (timing experiments)
 void attn_set_generation(int gen);   // 7 (default: 6 on deep grids, else 2) | 2 | 6 | 1: the first-round kernel (expects plain Q; same V^T layout)
 void ln_set_rows4_min(int rows);     // automatic rule: launches of at least this many rows take 4 rows per wave (65536)
+void ln_set_modes(bool on);         // LayerNorm: compile-time instantiations for the affine-only / modulation-only launches (default on)
 void ln_set_rows_per_wave(int rows);  // LayerNorm / ln_dot row kernels: 0 automatic | 1 | 4 rows per wave
 void ln_set_fixed_count(bool on);     // 1 (default): compile-time element counts for C = 1024 / 1536
 

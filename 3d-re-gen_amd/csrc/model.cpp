@@ -1401,6 +1401,7 @@ int r3g_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_splitk128")) gemm_set_splitk128(value != 0);
     else if (!strcmp(name, "conv_implicit")) gemm_set_conv_implicit(value != 0);
     else if (!strcmp(name, "gemm_xcd_walk")) gemm_set_xcd_walk(value != 0);
+    else if (!strcmp(name, "ln_modes")) ln_set_modes(value != 0);
     else if (!strcmp(name, "geo_lnd_fused")) g_geo_lnd_fused = value != 0;
     else if (!strcmp(name, "geo_ln3_fold")) g_geo_ln3_fold = value != 0;
     else if (!strcmp(name, "attn_variant")) attn_set_variant(value);

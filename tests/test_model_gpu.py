@@ -589,16 +589,20 @@ def test_layernorm_instantiations_are_bit_identical(wide):
         return c, z, out[start:start + count].clone(), f
     outs = []
     try:
-        for fixed, rows in ((1, 4), (1, 1), (0, 1), (0, 4)):
+        # (round 6: + the MODE instantiations -- the affine-only / modulation-only launches with their optional terms known at
+        # compile time, option ln_modes -- against the run-time form)
+        for fixed, rows, modes in ((1, 4, 1), (1, 1, 1), (0, 1, 1), (0, 4, 1), (1, 4, 0), (1, 1, 0)):
             ffi.check(L.r3g_set_option(b"ln_fixed", fixed))
             ffi.check(L.r3g_set_option(b"ln_rows", rows))
+            ffi.check(L.r3g_set_option(b"ln_modes", modes))
             outs.append(run())
     finally:
         ffi.check(L.r3g_set_option(b"ln_fixed", 1))
         ffi.check(L.r3g_set_option(b"ln_rows", 0))
+        ffi.check(L.r3g_set_option(b"ln_modes", 1))
     names = ("conditioner", "vae z", "grid logits", "flow_sample")
     bad = []
-    for (fixed, rows), o in zip(((1, 1), (0, 1), (0, 4)), outs[1:]):
+    for (fixed, rows), o in zip(((1, 1), (0, 1), (0, 4), (14, 4), (11, 1)), outs[1:]):
         for name, a, b in zip(names, outs[0], o):
             if not torch.equal(a, b):
                 bad.append("%s: ln_fixed=%d ln_rows=%d differs from (1, 4) in %d elements, max |d| %.3e"
