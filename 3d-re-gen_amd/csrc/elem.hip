@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
     float4 av[NVC], hv[NVC];
     const float *sc_held = nullptr, *sh_held = nullptr;
-#pragma unroll 1
-    for (int rr = 0; rr < RPW; ++rr, ++row) {
+    // one row of the wave (round 6: a function of its own, so that the one-row-per-wave instantiations are straight-line code --
+    // as the single iteration of a rolled loop the compiler kept the loop-carried copies: 69 v_mov per row)
+    auto one_row = [&](const int rr) __attribute__((always_inline)) -> bool {
         const bool more = RPW > 1 && rr + 1 < RPW && row + 1 < p.rows;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
             if (NV || i < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
-        const float mean = wave_sum(s) / (float)p.C;
+        // (C = 1024 at compile time: 1 / 1024 is a power of two, the product IS the quotient; other lengths keep the division)
+        const float mean = NV == 4 ? wave_sum(s) * (1.0f / 1024.0f) : wave_sum(s) / (float)p.C;
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NVC; ++i)
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
                 ss = fmaf(d, d, fmaf(c, c, fmaf(b, b, fmaf(a, a, ss))));   // spelled out: see the note on contraction below
             }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
+        const float rstd = rsqrtf((NV == 4 ? wave_sum(ss) * (1.0f / 1024.0f) : wave_sum(ss) / (float)p.C) + p.eps);
         uint16_t* y = p.y + (int64_t)batch * p.y_batch_stride + (int64_t)lrow * p.ldy;
         const bool to_fp8 = MODE < 0 && p.y8 != nullptr;      // wave-uniform
         float amax = 0.f;
@@ -149,15 +151,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             if (NV || i < nv) {
                 const int c = (i * 64 + lane) * 4;
                 float o[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
-                // every product and sum rounded on its own (__fmul_rn / __fadd_rn are never contracted): whether the
-                // compiler fuses `o * w + b` depends on the control flow around it, which differs between instantiations
-                if (has_w) { o[0] = __fmul_rn(o[0], wv[i].x); o[1] = __fmul_rn(o[1], wv[i].y); o[2] = __fmul_rn(o[2], wv[i].z); o[3] = __fmul_rn(o[3], wv[i].w); }
-                if (has_b) { o[0] = __fadd_rn(o[0], bv[i].x); o[1] = __fadd_rn(o[1], bv[i].y); o[2] = __fadd_rn(o[2], bv[i].z); o[3] = __fadd_rn(o[3], bv[i].w); }
-                if (has_sc) {
-                    o[0] = __fmul_rn(o[0], __fadd_rn(1.f, av[i].x)); o[1] = __fmul_rn(o[1], __fadd_rn(1.f, av[i].y));
-                    o[2] = __fmul_rn(o[2], __fadd_rn(1.f, av[i].z)); o[3] = __fmul_rn(o[3], __fadd_rn(1.f, av[i].w));
+                // every product and sum rounded on its own: whether the compiler fuses `o * w + b` depends on the control flow
+                // around it, which differs between instantiations.  __fmul_rn / __fadd_rn do NOT prevent that (they are inline
+                // header functions whose product and sum carry the translation unit's `contract` flag: in the straight-line
+                // compile-time-MODE kernels of round 6 they came out as v_pk_fma_f32 and every downstream value moved by a bf16
+                // rounding flip) -- plain operators under `fp contract(off)` do.
+                {
+#pragma clang fp contract(off)
+                    if (has_w) { o[0] = o[0] * wv[i].x; o[1] = o[1] * wv[i].y; o[2] = o[2] * wv[i].z; o[3] = o[3] * wv[i].w; }
+                    if (has_b) { o[0] = o[0] + bv[i].x; o[1] = o[1] + bv[i].y; o[2] = o[2] + bv[i].z; o[3] = o[3] + bv[i].w; }
+                    if (has_sc) {
+                        const float a0 = 1.f + av[i].x, a1 = 1.f + av[i].y, a2 = 1.f + av[i].z, a3 = 1.f + av[i].w;
+                        o[0] = o[0] * a0; o[1] = o[1] * a1; o[2] = o[2] * a2; o[3] = o[3] * a3;
+                    }
+                    if (has_sh) { o[0] = o[0] + hv[i].x; o[1] = o[1] + hv[i].y; o[2] = o[2] + hv[i].z; o[3] = o[3] + hv[i].w; }
                 }
-                if (has_sh) { o[0] = __fadd_rn(o[0], hv[i].x); o[1] = __fadd_rn(o[1], hv[i].y); o[2] = __fadd_rn(o[2], hv[i].z); o[3] = __fadd_rn(o[3], hv[i].w); }
                 if (to_fp8) {   // keep the finished values (the row's maximum decides their scale), write below
                     v[i] = make_float4(o[0], o[1], o[2], o[3]);
                     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
@@ -185,7 +193,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                     *reinterpret_cast<uint32_t*>(y8 + (i * 64 + lane) * 4) = (uint32_t)w;
                 }
         }
-        if (!more) break;
+        return more;
+    };
+    if constexpr (RPW == 1) {
+        (void)one_row(0);
+    } else {
+#pragma unroll 1
+        for (int rr = 0; rr < RPW; ++rr, ++row)
+            if (!one_row(rr)) break;
     }   // rows of this wave
 }
 
