@@ -776,9 +776,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                 __builtin_amdgcn_wave_barrier();
                 if (VM0 && ip == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (full) {      // the wave's 128 x 64 block lies inside the matrix: no predicates, one address product per tile
+                    // all LDS reads of the pass first, then the stores (round 6: hipcc kept two reads in flight and every store
+                    // waited out an LDS round trip -- s_memtime put the epilogue of the wave row that stores second at 9.6 k ticks)
+                    uint4 d[PI * 2];
+#pragma unroll
+                    for (int t = 0; t < PI * 2; ++t) d[t] = lds_ld4(rbase + roff(t * 8));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < PI * 2; ++t)
-                        *reinterpret_cast<uint4*>(crow + (int64_t)(ip * 2 + t) * step8) = lds_ld4(rbase + roff(t * 8));
+                        *reinterpret_cast<uint4*>(crow + (int64_t)(ip * 2 + t) * step8) = d[t];
                 } else {
 #pragma unroll
                     for (int t = 0; t < PI * 2; ++t) {
@@ -1682,6 +1688,18 @@ hipError_t launch_gemm8_fp8(const GemmArgs& p, const float* scale_a, const float
     return hipGetLastError();
 }
 
+#ifdef R3G_GEMM_STAMPS
+// Measurement build only (tools/gemm_stamps.py; never in libr3g.so): s_memtime sums per section of the persistent kernel's tile
+// loop, per wave of workgroup 8 (the second workgroup of XCD 0).
+__device__ unsigned long long g_gemm_stamps[8][8];
+#define R3G_STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0}
+#define R3G_STAMP(k) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
+#define R3G_STAMP_OUT do { if (blockIdx.x == 8 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_gemm_stamps[wid][k_] = st_acc[k_]; } } while (0)
+#else
+#define R3G_STAMP_DECL
+#define R3G_STAMP(k)
+#define R3G_STAMP_OUT
+#endif
 // ------------------------------------------------------------------------------------------------------------
 // Persistent form of the phased kernel: the grid is one workgroup per CU (balanced over the dispatch rounds) and every
 // workgroup walks tiles w, w + G, w + 2G, ...  Between two tiles it issues the LDS-DMA of the NEXT tile's first k-tile,
@@ -1759,13 +1777,42 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
 
     const uint16_t* srcA[2][2];
     const uint16_t* srcW[2][2];
+    // Round 6: INTERIOR tiles take their sources as four scalar bases + the lane's part of the address (32 bits, rebuilt from an
+    // opaque copy of the lane number so that it is not kept alive across the k-loop): 4 multiplies and 2 vector instructions per
+    // pointer where the general form (row clamp, 64-bit row x stride product per pointer: 24 quarter-rate multiplies) took ~5,
+    // twice per tile.
     auto set_sources = [&](const Tile& tl) {
         const GemmArgs& p = args_of(tl.second);
         const uint16_t* A = p.A + (int64_t)tl.batch * p.strideA;
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        // (not in the ln_3-fold kernel: its epilogue is at the register limit and the second path costs it three spilled bias vectors)
+        if (EPI != EPI_BF16_GELU_ERF_LNF && tl.m0 + BM <= p.M && tl.n0 + BN <= p.N) {   // wave-uniform
+            const uint32_t lda2 = (uint32_t)p.lda * 2u, ldw2 = (uint32_t)p.ldw * 2u;   // bytes per row (< 2^24: K is an int)
+            uint32_t loA[2], loW[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int lr = (wid * 2 + i) * 8 + (lane_s >> 3);
+                const int kc = (lane_s & 7) ^ ((lr >> 1) & 7);
+                loA[i] = (uint32_t)((lr >> 6) * 128 + (lr & 63)) * lda2 + (uint32_t)kc * 16u;
+                loW[i] = (uint32_t)((lr >> 5) * 64 + (lr & 31)) * ldw2 + (uint32_t)kc * 16u;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const char* ba = reinterpret_cast<const char*>(A + (int64_t)(tl.m0 + h * 64) * p.lda);
+                const char* bw = reinterpret_cast<const char*>(p.W + (int64_t)(tl.n0 + h * 32) * p.ldw);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    srcA[h][i] = reinterpret_cast<const uint16_t*>(ba + loA[i]);
+                    srcW[h][i] = reinterpret_cast<const uint16_t*>(bw + loW[i]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int lr = (wid * 2 + i) * 8 + (lane >> 3);        // row inside the half-tile
-            const int kc = (lane & 7) ^ ((lr >> 1) & 7);
+            const int lr = (wid * 2 + i) * 8 + (lane_s >> 3);        // row inside the half-tile
+            const int kc = (lane_s & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int ga = tl.m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
@@ -1901,13 +1948,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
     locate_u(my, cur, nk);
     set_sources(cur);
     stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
+    R3G_STAMP_DECL;
     for (;;) {
         // k-tile 0 is on its way (and, after the first tile, the previous tile's stores); k-tile 1 follows as in gemm8_kernel.
         // vmcnt(6) retires everything older than these six pieces -- exact whatever the epilogue issued.
+        R3G_STAMP(5);   // (set_sources again, loop overhead; the first tile: the prologue)
         stage_w(0, 1, 1); stage_a(0, 1, 1); stage_w(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // vmcnt(6) as the BUILTIN (0x0F76 = vmcnt 6, expcnt / lgkmcnt unconstrained), not as inline asm: the compiler's own wait
+        // insertion cannot see into inline asm, so it believed the previous tile's bias loads (issued on one path of the
+        // epilogue, consumed on another) still pending at the loop header and put an `s_waitcnt vmcnt(0)` in front of the first
+        // write to their registers (the clearing of the accumulators) -- AFTER k-tile 1 was issued: every tile of every
+        // persistent launch of rounds 2-5 drained its own prefetch there.
+        __builtin_amdgcn_s_waitcnt(0x0F76);
         R3G_BAR();
         if (wr == 1) R3G_BAR();   // the second wave row runs one barrier behind the first
+        R3G_STAMP(0);   // staging of k-tile 1, wait for k-tile 0 (and the previous tile's stores), opening barriers
         int t = 0;
         for (; t + 2 < nk; t += 2) {
             four_phases(I0{}, F{}, t);
@@ -1916,6 +1971,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
         four_phases(I0{}, T{}, t);
         four_phases(I1{}, T{}, t + 1);
         if (wr == 0) R3G_BAR();
+        R3G_STAMP(1);   // k-loop
 
         const Tile done = cur;
         // Round 5: the lane number the epilogue works with is made opaque once per tile.  Everything the epilogue derives from it
@@ -1944,6 +2000,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
             set_sources(cur);
             stage_w(0, 0, 0); stage_a(0, 0, 0); stage_w(1, 0, 0); stage_a(1, 0, 0);
         }
+        // (Round 6, measured and NOT kept: hipcc puts an s_waitcnt vmcnt(0) in front of the epilogue's first use of the bias -- it
+        // merges "eight newer operations" (a next tile was staged) with "none" (the last tile) -- so every tile waits there for its
+        // successor's k-tile 0.  Staging unconditionally + vmcnt(8) as a builtin removes the wait and changes nothing: the k-tile
+        // has landed by then (tools/gemm_stamps.py: epilogue 4.4 k ticks either way), while the fused-QKV kernels spill.)
+        R3G_STAMP(2);   // bias loads, next tile located, its sources, k-tile 0 issued
         {
             const GemmArgs& pp = args_of(done.second);
             auto run = [&](auto E) __attribute__((always_inline)) {
@@ -1966,6 +2027,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
                 run(std::integral_constant<int, EPI>{});
             }
         }
+        R3G_STAMP(3);   // epilogue (issue; the stores are waited for under stamp 0 of the next tile)
         if (!more) break;
         // the staging pointers are recomputed rather than kept alive across the epilogue (16 registers it needs); the
         // empty asm keeps the compiler from merging the two computations
@@ -1976,7 +2038,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs pa, GemmArgs pb, i
 #pragma unroll
             for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    R3G_STAMP_OUT;
 }
+
+#ifdef R3G_GEMM_STAMPS
+}  // anonymous namespace
+}  // namespace r3g
+extern "C" __attribute__((visibility("default"))) int r3g_debug_gemm_stamps(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(r3g::g_gemm_stamps), sizeof(unsigned long long) * 64);
+}
+namespace r3g {
+namespace {
+#endif
 
 bool g_gemm_xcd_walk = true;   // persistent kernel: an XCD walks one contiguous range of the tile order (round 5) | 0: rounds 2-4's walk
 bool g_gemm_persistent_qkv = true;   // fused QKV launches with more 256x256 tiles than CUs (the double blocks' img + txt pair) on the persistent phased kernel: round 4's 32-row passes cost +17 ms per object, round 6's 64-row passes through the idle k-tile buffer -4 ms (profiles/r06_ab.md)
