@@ -30,6 +30,9 @@ __global__ void k(unsigned long long* out, float* sink, int iters, float seed) {
             if (KIND == 13) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
             if (KIND == 14) asm volatile("v_exp_f16_e64 %0, %0" : "+v"(a[i]));
             if (KIND == 9 && i < 8) asm volatile("s_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
+            if (KIND == 15) asm volatile("v_mov_b32 %0, 0" : "=v"(a[i]));
+            if (KIND == 16 && (i & 1) == 0) asm volatile("v_mov_b64 %0, 0" : "=v"(*(f32x2*)&a[i]));
+            if (KIND == 17 && (i & 1) == 0) asm volatile("v_pk_mov_b32 %0, 0, 0" : "=v"(*(f32x2*)&a[i]));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -72,5 +75,8 @@ int main() {
     run<12>("v_pk_add_f16", 16);
     run<13>("v_cvt_pk_f16_f32", 16);
     run<9>("v_permlane32_swap", 8);
+    run<15>("v_mov_b32 0", 16);
+    run<16>("v_mov_b64 0", 8);
+    run<17>("v_pk_mov_b32 0, 0", 8);
     return 0;
 }
