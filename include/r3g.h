@@ -403,7 +403,7 @@ int r3g_prof_read_bytes(double* bytes, int n);
  * tile-choice rule | 1: round 2's | 0: round 1's first version), "attn_generation" (7 default: 6 where its
  * 256-query workgroups make four rounds of the device, otherwise 2 | 2 = four waves of 32 queries | 6 = four waves of 64
  * queries, bit-identical to 2 | 1 = the first-round kernel | 3, 4, 5 = pipelined / 8-wave variants), "attn_wide_min" (2048: work items of 256 queries from which attn_generation 7 takes generation 6), "ln_rows" (0 automatic | 1 | 4 rows per wave in the
- * LayerNorm / ln_dot row kernels), "ln_rows4_min" (65536: launches of at least this many rows take 4 rows per wave under the automatic rule), "ln_fixed" (1: their instantiations with a compile-time row length for C = 1024 / 1536), "attn_pipelined" (0), "attn_ablate"
+ * LayerNorm / ln_dot row kernels), "ln_rows4_min" (65536: launches of at least this many rows take 4 rows per wave under the automatic rule), "ln_fixed" (1: their instantiations with a compile-time row length for C = 1024 / 1536), "ln_modes" (1, round 6: for C = 1024 the affine-only and the modulation-only launches take instantiations with that decided at compile time -- bit-identical | 0: the generic kernel), "attn_pipelined" (0), "attn_ablate"
  * (timing-only masks, results are garbage), "floater_by_vertex" (0), "mc_rows" (4 | 8 | 16 | 32 node rows per wave in the marching-cubes row
  * kernel), "mc_deferred" (1: tiling selection batched per wave | 0: round 1's per-row kernel), "geo_resid_bf16" (1:
  * 16-bit residual stream in the geo decoder block), "geo_fp8" (0 default | 1: the geo decoder's c_q and MLP GEMMs on e4m3
