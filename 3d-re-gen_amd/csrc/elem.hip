@@ -13,6 +13,7 @@
 
 #include "kernels.h"
 #include "prof.h"
+#include "wave_sum.h"
 
 namespace r3g {
 namespace {
@@ -22,11 +23,7 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // v_cvt_pk_bf16_f32, round
     return *reinterpret_cast<const uint16_t*>(&h);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+// wave_sum: csrc/wave_sum.h (round 6: the xor butterfly on DPP / permlane swaps instead of six ds_bpermute round trips; same bits)
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------- LayerNorm (+affine) (+adaLN modulate) -> bf16

@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "gemm_common.h"
+#include "wave_sum.h"
 #include "kernels.h"
 #include "prof.h"
 
@@ -546,10 +547,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                             v[2 * k] = u[0];
                             v[2 * k + 1] = u[1];
                         }
+                        // (round 6: the three butterfly steps over the 8 lanes of a row by DPP -- csrc/wave_sum.h -- where hipcc had put nine
+                        // ds_bpermute round trips per 8 rows: 288 per tile)
                         float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                        s1 += __shfl_xor(s1, 1, 64);
-                        s1 += __shfl_xor(s1, 2, 64);
-                        s1 += __shfl_xor(s1, 4, 64);
+                        s1 += lane_xor<1>(s1);
+                        s1 += lane_xor<2>(s1);
+                        s1 += lane_xor<4>(s1);
                         const float mu = s1 * (1.0f / 64.0f);
                         float m2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -558,9 +561,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
                             m2 = fmaf(dv, dv, m2);
                             s3 = fmaf(v[k], k < 4 ? gw0[k] : gw1[k - 4], s3);
                         }
-                        m2 += __shfl_xor(m2, 1, 64); s3 += __shfl_xor(s3, 1, 64);
-                        m2 += __shfl_xor(m2, 2, 64); s3 += __shfl_xor(s3, 2, 64);
-                        m2 += __shfl_xor(m2, 4, 64); s3 += __shfl_xor(s3, 4, 64);
+                        m2 += lane_xor<1>(m2); s3 += lane_xor<1>(s3);
+                        m2 += lane_xor<2>(m2); s3 += lane_xor<2>(s3);
+                        m2 += lane_xor<4>(m2); s3 += lane_xor<4>(s3);
                         if (cc == 0 && m < p.M && n < p.N)
                             *reinterpret_cast<f32x4*>(p.lnd_part + ((int64_t)m * (p.N >> 6) + ((n0 >> 6) + wc)) * 4) = (f32x4){s1, m2, s3, 0.f};
                     }
