@@ -5,6 +5,9 @@
 #   newtests            the GPU tests added / changed this round
 #   attn [gens]         attention generations x variants (tools/bench_attn.py), e.g. 2v0,2v1,2v3 and 6v0,6v1,6v3
 #   abn <steps> <warmup> <opts_1> <opts_2> ...   bench.py once per option set, the whole list twice ("-" = no options)
+#   ablib <other libr3g.so> [steps] [warmup]     two BUILDS of the library against each other, A/B/A/B (R3G_LIBRARY; the other build: a
+#                       git worktree of the commit to compare with, built there, its .so copied next to this tree's)
+#   texprof             kernel trace of the texture step (tests/tex_stage_time.py) by kernel and by (kernel, grid)
 #   mc                  marching-cubes timeline on the blob and noise fields
 #   suite               the whole -m gpu suite
 #   bench               the driver's invocation of bench.py
